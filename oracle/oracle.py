@@ -1,0 +1,156 @@
+"""ctypes wrapper around oracle/_build/libctu_oracle.so.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/ctu_oracle.h.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libctu_oracle.so")
+_lib = None
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [
+        ("fs", ctypes.c_int), ("window", ctypes.c_int), ("wshift", ctypes.c_int), ("wfft", ctypes.c_int),
+        ("K", ctypes.c_int), ("B", ctypes.c_int), ("nfea", ctypes.c_int), ("D", ctypes.c_int),
+        ("htk_kind", ctypes.c_int), ("period", ctypes.c_uint), ("do_vad", ctypes.c_int),
+        ("phase_needed", ctypes.c_int), ("fb_power", ctypes.c_int), ("swap_out", ctypes.c_int),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "ctu_oracle.c"))
+    ):
+        subprocess.run(["make", "-C", _HERE, "-s", "all"], check=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.ctuo_create.restype = ctypes.c_void_p
+        L.ctuo_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_int]
+        L.ctuo_destroy.argtypes = [ctypes.c_void_p]
+        L.ctuo_get_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(Dims)]
+        L.ctuo_num_frames.restype = ctypes.c_long
+        L.ctuo_num_frames.argtypes = [ctypes.c_void_p, ctypes.c_long]
+        L.ctuo_process.restype = ctypes.c_long
+        L.ctuo_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+        L.ctuo_error.restype = ctypes.c_char_p
+        L.ctuo_error.argtypes = [ctypes.c_void_p]
+        L.ctuo_hamming.restype = ctypes.POINTER(ctypes.c_double)
+        L.ctuo_hamming.argtypes = [ctypes.c_void_p]
+        L.ctuo_preem.restype = ctypes.c_float
+        L.ctuo_preem.argtypes = [ctypes.c_void_p]
+        L.ctuo_fb_row.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)),
+                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.ctuo_last_power.restype = ctypes.POINTER(ctypes.c_double)
+        L.ctuo_last_power.argtypes = [ctypes.c_void_p]
+        L.ctuo_last_fbank.restype = ctypes.POINTER(ctypes.c_double)
+        L.ctuo_last_fbank.argtypes = [ctypes.c_void_p]
+        L.ctuo_burg_cepstrum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Oracle:
+    """One configured reference chain; `args` is the ctucopy command line (list of str, no argv[0])."""
+
+    def __init__(self, args):
+        L = lib()
+        self.args = [str(a) for a in args]
+        arr = (ctypes.c_char_p * len(self.args))(*[a.encode() for a in self.args])
+        err = ctypes.create_string_buffer(512)
+        self._h = L.ctuo_create(len(self.args), arr, err, 512)
+        if not self._h:
+            raise OracleError(err.value.decode())
+        d = Dims()
+        L.ctuo_get_dims(self._h, ctypes.byref(d))
+        self.dims = d
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ctuo_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def num_frames(self, nsamples):
+        return int(lib().ctuo_num_frames(self._h, int(nsamples)))
+
+    def process(self, pcm, want_vad=False):
+        """pcm: int16 array of one utterance -> float32 [rows, D] (and the VAD '0'/'1' bytes)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        T = self.num_frames(pcm.size)
+        if T < 0:
+            raise OracleError("IO: Signal shorter than one frame!")
+        rows = np.empty((max(T, 1), self.dims.D), dtype=np.float32)
+        vad = np.zeros(max(T, 1), dtype=np.uint8)
+        n = lib().ctuo_process(self._h, pcm.ctypes.data, pcm.size, rows.ctypes.data, vad.ctypes.data)
+        if n < 0:
+            raise OracleError(lib().ctuo_error(self._h).decode())
+        out = rows[:n].copy()
+        if want_vad:
+            return out, vad[:T].copy()
+        return out
+
+    def hamming(self):
+        return np.ctypeslib.as_array(lib().ctuo_hamming(self._h), shape=(self.dims.window,)).copy()
+
+    def preem(self):
+        return float(lib().ctuo_preem(self._h))
+
+    def fbank(self):
+        """Dense [B, K] float64 weights plus first/last non-zero bin per band."""
+        B, K = self.dims.B, self.dims.K
+        mat = np.zeros((B, K))
+        first = np.zeros(B, dtype=np.int32)
+        last = np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            p = ctypes.POINTER(ctypes.c_double)()
+            f = ctypes.c_int()
+            l = ctypes.c_int()
+            lib().ctuo_fb_row(self._h, b, ctypes.byref(p), ctypes.byref(f), ctypes.byref(l))
+            mat[b] = np.ctypeslib.as_array(p, shape=(K + 2,))[:K]
+            first[b], last[b] = f.value, l.value
+        return mat, first, last
+
+    def last_power(self):
+        return np.ctypeslib.as_array(lib().ctuo_last_power(self._h), shape=(self.dims.K,)).copy()
+
+    def last_fbank(self):
+        return np.ctypeslib.as_array(lib().ctuo_last_fbank(self._h), shape=(self.dims.B,)).copy()
+
+
+def burg_cepstrum(x, ncoefs):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    a = np.zeros(ncoefs)
+    c = np.zeros(ncoefs)
+    alpha = ctypes.c_double()
+    lib().ctuo_burg_cepstrum(x.ctypes.data, x.size, ncoefs, a.ctypes.data, c.ctypes.data, ctypes.byref(alpha))
+    return a, c, alpha.value
+
+
+def htk_bytes(rows, period, kind, big_endian=False):
+    """HTK file image as htkOUT writes it (src/io/out.cc:115-213): 12-byte header + float32 rows."""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    n, d = rows.shape if rows.ndim == 2 else (0, 0)
+    e = ">" if big_endian else "<"
+    hdr = np.array([n], dtype=e + "u4").tobytes() + np.array([period], dtype=e + "u4").tobytes() + \
+        np.array([4 * d], dtype=e + "u2").tobytes() + np.array([kind], dtype=e + "u2").tobytes()
+    return hdr + rows.astype(e + "f4").tobytes()
