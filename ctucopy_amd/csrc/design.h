@@ -1,0 +1,50 @@
+// Init-time table design on the host, in double precision, for the device kernels.
+//
+// Everything here is computed once per engine and must match the reference's init-time arithmetic
+// bit-for-bit in double before it is rounded to float for the GPU:
+//   Hamming window            src/io/in.cc:139-144
+//   filter bank               src/fea/fb.cc:100-132 (axes), 134-184 (PLP), 186-253 (grammar),
+//                             255-429 (triang/rect), 432-447 (first/last non-zero)
+//   DCT-II + lifter           src/fea/fea_impl.cc:81-131
+//   cosine iDFT for LPC       src/fea/fea_impl.cc:141-198
+//   TRAP Hamming / REDFT10    src/fea/fea_trap.cc:20-107
+//   output geometry           src/io/out.cc:95-113,145-171
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "opts.h"
+
+namespace ctu {
+
+enum class FeaKind { Spec, LogSpec, Dctc, Lpa, Lpc, TrapDct };
+
+struct DesignError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct Design {
+    Opts o;  // options after the filter-bank constructor's overrides (PLP forces bark/eqld/inld)
+    int window = 0, wshift = 0, wfft = 0, K = 0, B = 0;
+    FeaKind kind = FeaKind::Dctc;
+    int nfea = 0;      // internal feature vector length (fvec)
+    int D = 0;         // floats per output row
+    int htk_kind = 0;  // HTK parameter kind incl. qualifier bits
+    unsigned period = 0;
+
+    std::vector<double> hamming;             // [window]
+    std::vector<std::vector<double>> fb;     // [B][K]
+    std::vector<int> fb_first, fb_last;      // first / last non-zero bin of each band
+    std::vector<double> dct;                 // [(ncep+1)][B]: sqrt(2/B) * cos(...) * lifter, row i = c_i
+    std::vector<double> lifter;              // [ncep]
+    std::vector<double> idft;                // [(p+1)][B]: R[k] = sum_n idft[k][n] * Y[n]
+    std::vector<double> trap;                // [ndct][traplen]: mean-removal + Hamming + REDFT10 folded
+    // output row: slot of fvec[i] in the written row (-1 = not written); E slot or -1
+    std::vector<int> row_slot;
+    int e_slot = -1;
+
+    explicit Design(const Opts &opts);
+};
+
+}  // namespace ctu

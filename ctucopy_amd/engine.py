@@ -1,0 +1,202 @@
+"""ctypes binding of include/ctu_engine.h -- the only way Python reaches the hot path.
+
+PyTorch is used purely as plumbing (device buffers and streams); the computation is the HIP library.
+There is no CPU fallback: creating an Engine without the built library or without a GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+CTU_OK, CTU_ERR_OPTS, CTU_ERR_UNSUPPORTED, CTU_ERR_DEVICE, CTU_ERR_INPUT = 0, -1, -2, -3, -4
+
+
+class CtuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [("fs", ctypes.c_int32), ("window", ctypes.c_int32), ("wshift", ctypes.c_int32),
+                ("wfft", ctypes.c_int32), ("nbins", ctypes.c_int32), ("nbands", ctypes.c_int32),
+                ("row_floats", ctypes.c_int32), ("htk_kind", ctypes.c_int32), ("htk_period", ctypes.c_uint32),
+                ("has_vad", ctypes.c_int32), ("swap_out", ctypes.c_int32), ("pcm_align", ctypes.c_int32)]
+
+
+# every symbol include/ctu_engine.h declares (checked by tests/test_abi.py)
+EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
+           "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
+           "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
+           "ctu_engine_run_host", "ctu_engine_last_kernel_ms"]
+
+_lib = None
+
+
+def load_library():
+    """Loads ctucopy_amd/libctu_engine.so (must have been built: __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        raise CtuError(CTU_ERR_DEVICE, f"{_build.LIB} is missing: run __graft_entry__.build() (hipcc, gfx950) first; "
+                                       "there is no CPU fallback")
+    L = ctypes.CDLL(_build.LIB)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    argv_t = ctypes.POINTER(ctypes.c_char_p)
+    L.ctu_engine_create.argtypes = [ctypes.c_int, argv_t, ctypes.c_int, ctypes.POINTER(vp)]
+    L.ctu_engine_destroy.argtypes = [vp]
+    L.ctu_create_error.restype = ctypes.c_char_p
+    L.ctu_last_error.restype = ctypes.c_char_p
+    L.ctu_last_error.argtypes = [vp]
+    L.ctu_engine_dims.argtypes = [vp, ctypes.POINTER(Dims)]
+    L.ctu_config_dims.argtypes = [ctypes.c_int, argv_t, ctypes.POINTER(Dims)]
+    L.ctu_config_table.restype = i64
+    L.ctu_config_table.argtypes = [ctypes.c_int, argv_t, ctypes.c_char_p, vp, i64]
+    L.ctu_num_frames.restype = i64
+    L.ctu_num_frames.argtypes = [vp, i64]
+    L.ctu_plan_create.argtypes = [vp, ctypes.POINTER(i64), i32, ctypes.POINTER(vp)]
+    L.ctu_plan_destroy.argtypes = [vp]
+    L.ctu_plan_sample_offsets.restype = ctypes.POINTER(i64)
+    L.ctu_plan_sample_offsets.argtypes = [vp]
+    L.ctu_plan_row_offsets.restype = ctypes.POINTER(i64)
+    L.ctu_plan_row_offsets.argtypes = [vp]
+    L.ctu_plan_total_samples.restype = i64
+    L.ctu_plan_total_samples.argtypes = [vp]
+    L.ctu_plan_total_frames.restype = i64
+    L.ctu_plan_total_frames.argtypes = [vp]
+    L.ctu_engine_run.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ctu_engine_run_host.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ctu_engine_last_kernel_ms.restype = ctypes.c_float
+    L.ctu_engine_last_kernel_ms.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _argv(args):
+    args = [str(a).encode() for a in args]
+    return len(args), (ctypes.c_char_p * len(args))(*args)
+
+
+def config_dims(args):
+    """Geometry of a command line without touching a GPU (parse + host-side table design)."""
+    L = load_library()
+    d = Dims()
+    n, arr = _argv(args)
+    rc = L.ctu_config_dims(n, arr, ctypes.byref(d))
+    if rc != CTU_OK:
+        raise CtuError(rc, L.ctu_create_error().decode())
+    return d
+
+
+def config_table(args, name):
+    """Host-designed table (float64 numpy) by name; see ctu_config_table in include/ctu_engine.h."""
+    L = load_library()
+    n, arr = _argv(args)
+    cnt = L.ctu_config_table(n, arr, name.encode(), None, 0)
+    if cnt < 0:
+        raise CtuError(int(cnt), L.ctu_create_error().decode())
+    out = np.zeros(int(cnt), dtype=np.float64)
+    L.ctu_config_table(n, arr, name.encode(), out.ctypes.data, cnt)
+    return out
+
+
+class Plan:
+    """Batch layout: where each utterance sits in the packed PCM arena and in the output rows."""
+
+    def __init__(self, engine, nsamples):
+        L = load_library()
+        self.engine = engine
+        ns = np.ascontiguousarray(nsamples, dtype=np.int64)
+        self.n_utt = int(ns.size)
+        h = ctypes.c_void_p()
+        rc = L.ctu_plan_create(engine._h, ns.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), self.n_utt, ctypes.byref(h))
+        if rc != CTU_OK:
+            raise CtuError(rc, L.ctu_last_error(engine._h).decode())
+        self._h = h
+        self.nsamples = ns
+        self.sample_off = np.ctypeslib.as_array(L.ctu_plan_sample_offsets(h), shape=(self.n_utt + 1,)).copy()
+        self.row_off = np.ctypeslib.as_array(L.ctu_plan_row_offsets(h), shape=(self.n_utt + 1,)).copy()
+        self.total_samples = int(L.ctu_plan_total_samples(h))
+        self.total_frames = int(L.ctu_plan_total_frames(h))
+
+    def pack(self, utterances):
+        """int16 arena (numpy) holding the utterances at their planned offsets."""
+        arena = np.zeros(self.total_samples, dtype=np.int16)
+        for u, off in zip(utterances, self.sample_off[:-1]):
+            arena[off:off + len(u)] = u
+        return arena
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().ctu_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Engine:
+    """One configured chain on one GPU; `args` is the ctucopy command line (list of str)."""
+
+    def __init__(self, args, device=0):
+        L = load_library()
+        n, arr = _argv(args)
+        h = ctypes.c_void_p()
+        rc = L.ctu_engine_create(n, arr, int(device), ctypes.byref(h))
+        if rc != CTU_OK:
+            raise CtuError(rc, L.ctu_create_error().decode())
+        self._h = h
+        self.device = int(device)
+        self.dims = Dims()
+        L.ctu_engine_dims(h, ctypes.byref(self.dims))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().ctu_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def num_frames(self, nsamples):
+        return int(load_library().ctu_num_frames(self._h, int(nsamples)))
+
+    def plan(self, nsamples):
+        return Plan(self, nsamples)
+
+    def _check(self, rc):
+        if rc != CTU_OK:
+            raise CtuError(rc, load_library().ctu_last_error(self._h).decode())
+
+    def run_device(self, plan, pcm, rows=None, vad=None, stream=None):
+        """pcm: torch int16 CUDA tensor [plan.total_samples]; returns the float32 rows tensor (async)."""
+        import torch
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.numel() >= plan.total_samples
+        if rows is None:
+            rows = torch.empty((plan.total_frames, self.dims.row_floats), dtype=torch.float32, device=pcm.device)
+        s = stream if stream is not None else torch.cuda.current_stream(pcm.device)
+        self._check(load_library().ctu_engine_run(self._h, plan._h, pcm.data_ptr(), rows.data_ptr(),
+                                                  vad.data_ptr() if vad is not None else None, s.cuda_stream))
+        return rows
+
+    def run_host(self, plan, arena):
+        """numpy int16 arena in, numpy float32 rows out (H2D + kernels + D2H inside the library)."""
+        arena = np.ascontiguousarray(arena, dtype=np.int16)
+        assert arena.size >= plan.total_samples
+        rows = np.empty((plan.total_frames, self.dims.row_floats), dtype=np.float32)
+        per = np.zeros(plan.n_utt, dtype=np.int64)
+        self._check(load_library().ctu_engine_run_host(self._h, plan._h, arena.ctypes.data, rows.ctypes.data, None,
+                                                       per.ctypes.data))
+        return rows
+
+    def last_kernel_ms(self):
+        return float(load_library().ctu_engine_last_kernel_ms(self._h))
+
+    def extract(self, utterances):
+        """Convenience: list of int16 arrays -> list of [frames, D] float32 arrays."""
+        plan = self.plan([len(u) for u in utterances])
+        rows = self.run_host(plan, plan.pack(utterances))
+        out = [rows[plan.row_off[i]:plan.row_off[i + 1]] for i in range(plan.n_utt)]
+        plan.close()
+        return out

@@ -1,0 +1,112 @@
+/*
+ * ctu_engine.h -- C ABI of the MI355X (gfx950) framewise feature engine.
+ *
+ * This is the drop-in boundary for CtuCopy's per-frame hot path.  The reference has no FFI; its
+ * "operator API" is the set of per-stage objects BATCH wires together by pointer and drives once per
+ * frame (src/io/batch.cc:24-69 wiring, :205-228 per-frame dispatch, :326-421 list loop).  The calls
+ * below replace, for a whole list of files at once:
+ *
+ *   new opts(argc,argv) + new BATCH(o)        -> ctu_engine_create        (src/io/opts.cc:27-194, src/io/batch.cc:24-69)
+ *   scanning the -S list / IN::new_file       -> ctu_plan_create          (src/io/batch.cc:349-371, src/io/in.cc:264-279)
+ *   while(in->get_frame()) process_frame();   -> ctu_engine_run[_host]    (src/io/batch.cc:402-407 incl. flush_fea)
+ *     rawIN::get_frame after loadframe           (src/io/in.cc:343-417)
+ *     NR::process_frame                          (src/nr/nr.cc:95-140)
+ *     FB::project_frame                          (src/fea/fb.cc:72-86)
+ *     FEA::process_frame / flush_frame           (src/fea/fea_impl.cc:104-131,163-284, src/fea/fea_trap.cc:53-127)
+ *     VAD::process_frame .. flush                (src/vad/vad.cc:692-745, src/io/batch.cc:230-249)
+ *     htkOUT::save_frame reorder + (float)       (src/io/out.cc:174-203; the fwrite stays with the caller)
+ *   throw "literal" caught in main()          -> negative return + ctu_last_error (src/main.cpp:54-60)
+ *
+ * File decoding (rawIN::loadframe, a-law/mu-law, WAVE headers) and the HTK/pfile/ark writers stay on
+ * the caller's side of this ABI ("src/io left as-is"); the bundled `ctucopy` executable provides them.
+ *
+ * Plain pointers and sizes only.  Device pointers are HIP device addresses on the engine's device.
+ * There is no CPU fallback: every entry point that computes fails with CTU_ERR_DEVICE when no gfx950
+ * device is usable.
+ */
+#ifndef CTU_ENGINE_H
+#define CTU_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ctu_engine ctu_engine;
+typedef struct ctu_plan ctu_plan;
+
+enum {
+    CTU_OK = 0,
+    CTU_ERR_OPTS = -1,        /* command line rejected (message = the reference's text) */
+    CTU_ERR_UNSUPPORTED = -2, /* valid ctucopy configuration outside the accelerated path */
+    CTU_ERR_DEVICE = -3,      /* no usable HIP device / HIP runtime error */
+    CTU_ERR_INPUT = -4,       /* bad argument, or "IO: Signal shorter than one frame!" */
+};
+
+/* Geometry of a configured chain (all derived as in the reference, see each field). */
+typedef struct {
+    int32_t fs;
+    int32_t window;     /* src/io/opts.cc:259 */
+    int32_t wshift;     /* src/io/opts.cc:260 */
+    int32_t wfft;       /* src/io/opts.cc:277-280 */
+    int32_t nbins;      /* wfft/2+1, src/io/opts.cc:283 */
+    int32_t nbands;     /* src/fea/fb.cc:183,289-302 */
+    int32_t row_floats; /* floats per output row incl. c0/E, src/io/out.cc:95-113 */
+    int32_t htk_kind;   /* src/io/out.cc:147-159 */
+    uint32_t htk_period;/* src/io/out.cc:146 */
+    int32_t has_vad;    /* a VAD byte per frame is produced, src/io/batch.cc:34-38 */
+    int32_t swap_out;   /* caller must byte-swap on write (-endian_out big), src/io/opts.cc:287 */
+    int32_t pcm_align;  /* utterance starts inside the packed PCM arena are multiples of this many samples */
+} ctu_dims;
+
+/* argv = the ctucopy command line without argv[0] (flags of src/io/opts.cc:644-846, incl. -C <file>).
+ * device = HIP ordinal.  On failure *out is NULL and ctu_create_error() holds the message. */
+int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine **out);
+void ctu_engine_destroy(ctu_engine *);
+const char *ctu_create_error(void);
+const char *ctu_last_error(const ctu_engine *);
+int ctu_engine_dims(const ctu_engine *, ctu_dims *out);
+
+/* Parse + design only (no device needed): used by host-side tools and CPU tests. */
+int ctu_config_dims(int argc, const char *const *argv, ctu_dims *out);
+
+/* Host-designed tables in double precision (no device needed), for inspection and tests:
+ * name = "hamming" [window] | "fbank" [nbands*nbins] | "fb_first" | "fb_last" [nbands] |
+ *        "dct" [(ncep+1)*nbands] | "idft" [(p+1)*nbands] | "trap" [ndct*traplen] | "lifter" [ncep].
+ * Returns the number of values (written up to cap), or a negative error code. */
+int64_t ctu_config_table(int argc, const char *const *argv, const char *name, double *out, int64_t cap);
+
+/* floor((n - (window-wshift)) / wshift); -1 when n < window-wshift (src/io/in.cc:277,314). */
+int64_t ctu_num_frames(const ctu_engine *, int64_t nsamples);
+
+/* A plan fixes the batch layout: utterance i has utt_nsamples[i] samples and lives in the packed
+ * int16 arena at sample offset ctu_plan_sample_offsets()[i] (offsets are multiples of pcm_align; the
+ * gaps are never read).  Its output rows start at row ctu_plan_row_offsets()[i].  Both offset arrays
+ * have n_utt+1 entries and stay valid until ctu_plan_destroy. */
+int ctu_plan_create(ctu_engine *, const int64_t *utt_nsamples, int32_t n_utt, ctu_plan **out);
+void ctu_plan_destroy(ctu_plan *);
+const int64_t *ctu_plan_sample_offsets(const ctu_plan *);
+const int64_t *ctu_plan_row_offsets(const ctu_plan *);
+int64_t ctu_plan_total_samples(const ctu_plan *);
+int64_t ctu_plan_total_frames(const ctu_plan *);
+
+/* Device-resident run: d_pcm = packed arena (int16, total_samples), d_rows = total_frames*row_floats
+ * floats in writer order (c1..cN,c0[,E]), d_vad = total_frames bytes '0'/'1' or NULL.
+ * stream = hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
+int ctu_engine_run(ctu_engine *, const ctu_plan *, const int16_t *d_pcm, float *d_rows, uint8_t *d_vad, void *stream);
+
+/* Host-buffer convenience: H2D, run, D2H, synchronised on return.  rows_per_utt (optional, n_utt
+ * entries) receives the number of rows actually produced per utterance (< frames only with
+ * -vad_apply_mode drop). */
+int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
+                        int64_t *rows_per_utt);
+
+/* Timing of the last ctu_engine_run on this engine, measured with HIP events on the run's stream
+ * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */
+float ctu_engine_last_kernel_ms(ctu_engine *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

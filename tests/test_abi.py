@@ -1,0 +1,81 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every declared symbol, parses like the oracle,
+designs bit-identical tables, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ctucopy_amd
+from ctucopy_amd import CtuError, config_dims, config_table
+from ctucopy_amd import build as cbuild
+from ctucopy_amd import engine as ceng
+from oracle.oracle import Oracle, OracleError
+from tests.util import C1, C2, C3, C4, C5
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    cbuild.build_engine()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ctu_engine.h")).read()
+    declared = set(re.findall(r"\b(ctu_[a-z_]+)\s*\(", hdr))
+    assert declared == set(ceng.EXPORTS)
+    lib = ctypes.CDLL(cbuild.LIB)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize("cfg", [C1, C2, C3, C5, C2 + ["-fea_E", "on"], C2 + ["-fea_c0", "off"],
+                                 "-fs 8000 -preset plpc".split(), "-fs 16000 -preset mfcc -fea_kind logspec".split(),
+                                 "-fs 16000 -preset mfcc -fb_shape rect -fb_definition 0-4000Hz:1-8/8filters,4000-8000Hz:1-4/4filters".split()])
+def test_geometry_matches_oracle(cfg):
+    d, o = config_dims(cfg), Oracle(cfg).dims
+    assert (d.fs, d.window, d.wshift, d.wfft, d.nbins, d.nbands, d.row_floats, d.htk_kind, d.htk_period) == \
+        (o.fs, o.window, o.wshift, o.wfft, o.K, o.B, o.D, o.htk_kind, o.period)
+
+
+@pytest.mark.parametrize("cfg", [C1, C2, C3, C5, "-fs 8000 -preset plpc".split(),
+                                 "-fs 16000 -preset mfcc -fb_scale bark -fb_eqld on".split(),
+                                 "-fs 16000 -preset mfcc -fb_scale expolog -fb_norm off".split(),
+                                 "-fs 16000 -preset mfcc -fb_scale lin -fb_shape rect -fb_definition 12filters".split()])
+def test_host_design_tables_bit_identical_to_oracle(cfg):
+    o = Oracle(cfg)
+    assert np.array_equal(config_table(cfg, "hamming"), o.hamming())
+    mat, first, last = o.fbank()
+    assert np.array_equal(config_table(cfg, "fbank").reshape(mat.shape), mat)
+    assert np.array_equal(config_table(cfg, "fb_first"), first)
+    assert np.array_equal(config_table(cfg, "fb_last"), last)
+
+
+def test_error_texts_follow_the_reference():
+    for cfg, pat in ((["-preset", "mfcc"], "sampling rate"), ("-fs 16000 -bogus 1".split(), "Syntax error"),
+                     ("-fs 16000 -preset nope".split(), "Unknown preset"),
+                     ("-fs 16000 -preset mfcc -preem 1.0".split(), "Preemphasis"),
+                     ("-fs 16000 -preset mfcc -fb_definition 3x".split(), "parse error"),
+                     ("-fs 16000 -preset mfcc -fea_kind trapdct,100,5".split(), "must be odd")):
+        with pytest.raises(CtuError, match=pat):
+            config_dims(cfg)
+        with pytest.raises(OracleError, match=pat):
+            Oracle(cfg)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(CtuError) as ei:
+        ctucopy_amd.Engine(C2)
+    assert ei.value.code == ceng.CTU_ERR_DEVICE and "no CPU fallback" in str(ei.value)
+
+
+def test_unsupported_configurations_are_reported_not_approximated():
+    for cfg in (C2 + ["-dither", "1.0"], C2 + ["-nr_mode", "hwss", "-vad", "burg"], C2 + ["-fea_delta", "d_a"]):
+        with pytest.raises(CtuError) as ei:
+            ctucopy_amd.Engine(cfg)
+        assert ei.value.code == ceng.CTU_ERR_UNSUPPORTED

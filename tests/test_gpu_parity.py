@@ -1,0 +1,103 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerance (BASELINE.json north_star): cepstra within 1e-4 relative, taken norm-wise as
+|a-b| <= 1e-4 * max(|b|, 1) (hard part 1); frame counts and row widths exact.
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.util import C1, C2, C3, C5, sig, synth_utt
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def rel_err(got, ref):
+    return float((np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)).max()) if ref.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ctucopy_amd import Engine as E, load_library
+    load_library()  # fails loudly when the HIP extension is missing
+    return E
+
+
+def _check(Engine, cfg, utts, tol=TOL):
+    eng = Engine(cfg)
+    got = eng.extract(utts)
+    orc = Oracle(cfg)
+    worst = 0.0
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        assert np.isfinite(g).all()
+        worst = max(worst, rel_err(g, ref))
+    assert worst <= tol, worst
+    return worst
+
+
+def test_c1_bundled_signals_mfcc(Engine):
+    got = Engine(C1).extract([sig("CS0"), sig("CS3")])
+    assert [g.shape for g in got] == [(594, 13), (592, 13)]
+    _check(Engine, C1, [sig("CS0"), sig("CS3")])
+
+
+def test_c2_preset_mfcc(Engine):
+    utts = [sig("CS0"), sig("CS3")] + [synth_utt(s, n) for s, n in ((1, 48000), (2, 16001), (3, 400), (4, 240), (5, 10400 + 7))]
+    _check(Engine, C2, utts)
+
+
+def test_ragged_batch_and_tile_edges(Engine):
+    # lengths chosen around the 64-frame tile: 1, 63, 64, 65, 128, 129 frames and an empty (0-frame) utterance
+    frames = [1, 63, 64, 65, 128, 129, 0, 200]
+    utts = [synth_utt(100 + i, 240 + 160 * f + (i % 3)) for i, f in enumerate(frames)]
+    eng = Engine(C2)
+    got = eng.extract(utts)
+    assert [g.shape[0] for g in got] == frames
+    orc = Oracle(C2)
+    for u, g in zip(utts, got):
+        assert rel_err(g, orc.process(u)) <= TOL
+
+
+def test_batch_invariance(Engine):
+    # an utterance's rows do not depend on what else is in the batch (bit-exact)
+    eng = Engine(C2)
+    a, b, c = synth_utt(7, 30000), synth_utt(8, 12345), synth_utt(9, 50001)
+    alone = eng.extract([b])[0]
+    mixed = eng.extract([a, b, c])[1]
+    assert np.array_equal(alone, mixed)
+
+
+@pytest.mark.parametrize("extra", [["-preem", "0"], ["-remove_dc", "off"], ["-fea_c0", "off"], ["-fea_lifter", "0"],
+                                   ["-fea_ncepcoefs", "20"], ["-fb_definition", "40filters"], ["-w", "20", "-s", "5"],
+                                   ["-fb_scale", "bark"], ["-fb_scale", "expolog"], ["-fb_eqld", "on", "-fb_inld", "on"],
+                                   ["-fb_shape", "rect", "-fb_definition", "20filters"], ["-fb_power", "off"],
+                                   ["-fb_definition", "100-4000Hz:1-10/10filters,4000-8000Hz:3-6/8filters"]])
+def test_mfcc_option_sweep(Engine, extra):
+    _check(Engine, C2 + extra, [synth_utt(21, 20000), sig("CS3")[:24000]])
+
+
+@pytest.mark.parametrize("kind", ["spec", "logspec"])
+def test_spectral_kinds(Engine, kind):
+    _check(Engine, C2 + ["-fea_kind", kind], [synth_utt(31, 20000), sig("CS0")[:16000]])
+
+
+def test_c3_plp(Engine):
+    _check(Engine, C3, [sig("CS0"), sig("CS3"), synth_utt(41, 32000)])
+    _check(Engine, C3 + ["-fea_kind", "lpa"], [synth_utt(42, 16000)])
+    _check(Engine, C3 + ["-fea_ncepcoefs", "16", "-fea_lporder", "10"], [synth_utt(43, 16000)])
+
+
+def test_exten_16k(Engine):
+    cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
+    _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
+    _check(Engine, C2 + ["-nr_mode", "exten"], [synth_utt(53, 20000)])
+
+
+def test_c5_trapdct(Engine):
+    _check(Engine, C5, [sig("CS3"), synth_utt(61, 30000)])
