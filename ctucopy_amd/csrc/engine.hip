@@ -30,49 +30,46 @@
 #include "design.h"
 #include "opts.h"
 
+
 namespace {
 
 constexpr int TILE = 64;       // frames per tile (= lanes of the per-frame phase)
 constexpr int WG = 512;        // threads per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
 constexpr int PSTRIDE = 257;   // floats per P-tile row (odd: lane-per-frame column reads are conflict-free)
-constexpr int AUX_ROWS = 62;   // [AUX_ROWS][64] floats of per-band / per-coefficient staging
+constexpr int AUX_ROWS = 62;   // [AUX_ROWS][64] floats of per-band / per-coefficient / output staging
 constexpr int LDS_FLOATS = TILE * PSTRIDE + AUX_ROWS * 64;
 static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU need <= 80 KiB each");
-constexpr int MAX_LP = 20;     // Levinson order limit of the in-register recursion
-constexpr int PCM_ALIGN = 8;
+constexpr int MAX_LP = 16;     // Levinson order limit of the in-register recursion
+constexpr int PCM_ALIGN = 8;   // utterance starts are multiples of this many samples
+constexpr int PCM_HEAD = 8;    // samples of padding before the first utterance (x[-2..-1] of frame 0 is loaded)
+constexpr int PCM_TAIL = 64;   // padding after the last one (loads run to the end of the 32-sample row)
+
+// Per-lane constant record, one per l16 = lane & 15, streamed from L1 every pass instead of pinning
+// 70+ VGPRs:  [0,32) Hamming pairs (w[32j+2l], w[32j+2l+1]) j=0..15 | [32,64) 1/0 "sample is inside the
+// window" pairs for DC removal | [64,96) inter-stage twiddles W256^(l*k1), k1=1..15 (+pad) |
+// [96,112) W512^(l+16*k2), k2=0..7
+constexpr int LC_WIN = 0, LC_MASK = 32, LC_TW = 64, LC_UT = 96, LANEC = 112;
 
 enum FeatMode { FEAT_SPEC = 0, FEAT_LOGSPEC = 1, FEAT_DCTC = 2, FEAT_LPC = 3, FEAT_LPA = 4, FEAT_LOGMEL_SCRATCH = 5 };
 
 struct KParams {
     const int16_t *pcm;
     float *rows;
-    float *logmel;            // [total_frames][B] scratch (TRAP only)
+    float *logmel;              // [total_frames][B] scratch (TRAP only)
     const int4 *tiles;
     const int64_t *sample_off;  // per utterance
     const int64_t *row_off;     // per utterance
-    int n_tiles;
-    // tables
-    const float *win;         // [512] zero padded
-    const float2 *tw1;        // [16][16]  W256^(n2*k1), index k1*16+n2
-    const float2 *tw2;        // [129]     W512^k
-    const int *band_first;    // [B] first bin (padded range)
-    const int *band_len;      // [B] multiple of 4
-    const int *band_off;      // [B] offset into fbw
-    const float *fbw;         // packed band weights
-    const int *grp_start;     // [NWAVE+1] bands of wave g: [grp_start[g], grp_start[g+1])
-    const float *dct;         // [nfea][B]  (dctc)   or idft [(p+1)][B] (lpc)
-    const float *lifter;      // [ncep]
-    const int *row_slot;      // [nfea]
-    // scalars
-    int window, wshift, B, nfea, D, ncep, lporder;
-    float preem;
-    int remove_dc, fb_power, fb_inld, lifter_on;
-    int nr_exten;
-    float nr_p, nr_a;
-    int by_utt;               // tiles are walked utterance by utterance (sequential state)
     const int *utt_tile_start;  // [n_utt+1] (by_utt)
-    int n_utt;
+    const float *lanec;         // [16][LANEC]
+    const float *ftab;          // band weights at 0, then dct/idft table at dct_off, lifter at lift_off
+    const int *itab;            // band_first[B] | band_len[B] | band_off[B] | grp_start[NWAVE+1] | row_slot[nfea]
+    int n_tiles, n_utt, by_utt;
+    int wshift, B, nfea, D, ncep, lporder;
+    int dct_off, lift_off;
+    float preem, inv_window;
+    int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
+    float nr_p, nr_a;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -115,6 +112,10 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k = 0; k < 16; k++) v[k] = t[k];
 }
 
+struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-byte aligned
+    uint32_t lo, hi;
+};
+
 // NZ = number of 32-sample rows that can hold non-zero input (ceil(window/32)); rows >= NZ are
 // literal zeros so the compiler prunes the first butterflies.
 template <int NZ, int FEAT>
@@ -128,22 +129,11 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
     const int fg = lane >> 4;    // frame slot within the wave pass
-
-    // ---- per-lane constants (live across tiles)
-    float w0[NZ], w1[NZ];
-#pragma unroll
-    for (int j = 0; j < NZ; j++) {
-        w0[j] = p.win[32 * j + 2 * l16];
-        w1[j] = p.win[32 * j + 2 * l16 + 1];
-    }
-    float2 tw[16];
-#pragma unroll
-    for (int k1 = 1; k1 < 16; k1++) tw[k1] = p.tw1[k1 * 16 + l16];
-    float2 ut[8];
-#pragma unroll
-    for (int k2 = 0; k2 < 8; k2++) ut[k2] = p.tw2[l16 + 16 * k2];
-    const int partner = (lane & 48) | ((16 - l16) & 15);
-    const float inv_window = 1.0f / (float)p.window;
+    const float4 *lc = reinterpret_cast<const float4 *>(p.lanec + l16 * LANEC);
+    const int partner = ((lane & 48) | ((16 - l16) & 15)) << 2;  // byte address for ds_bpermute
+    const int B = p.B;
+    const int *band_first = p.itab, *band_len = p.itab + B, *band_off = p.itab + 2 * B;
+    const int *grp_start = p.itab + 3 * B, *row_slot = p.itab + 3 * B + NWAVE + 1;
 
     // exten NR state: thread = bin
     float navg = 0.95f, yavg = 0.05f;
@@ -169,25 +159,28 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                 const int f = wave * 8 + it * 4 + fg;               // frame slot in tile
                 const int fc = f < nvalid ? f : nvalid - 1;         // clamp (duplicates are never stored)
                 const int t = t0 + fc;
-                const int16_t *x = p.pcm + sbase + (int64_t)t * p.wshift;
+                // samples x[i0-2 .. i0+1] of row j sit at x + 32 j + 2 l16 - 2 (4-byte aligned)
+                const int16_t *x = p.pcm + sbase + (int64_t)t * p.wshift + 2 * l16 - 2;
 
                 float2 v[16];
                 float dc = 0.f;
+                {
+                    pcm4 q[NZ];
 #pragma unroll
-                for (int j = 0; j < NZ; j++) {
-                    const int i0 = 32 * j + 2 * l16;  // sample index of the even sample
-                    float y0 = 0.f, y1 = 0.f;
-                    if (i0 < p.window) {
-                        const uint32_t pr = *reinterpret_cast<const uint32_t *>(x + i0);
-                        const float x0 = (float)(int16_t)(pr & 0xffffu);
-                        const float x1 = (float)(int16_t)(pr >> 16);
-                        float xm = 0.f;
-                        if (i0 > 0 || t > 0) xm = (float)x[i0 - 1];
-                        y0 = w0[j] * (x0 - p.preem * xm);
-                        y1 = w1[j] * (x1 - p.preem * x0);  // w1 is 0 beyond the window
+                    for (int j = 0; j < NZ; j++) q[j] = *reinterpret_cast<const pcm4 *>(x + 32 * j);
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
+                        const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
+                        float xm = (float)(int16_t)(q[j].lo >> 16);
+                        const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
+                        const float x1 = (float)(int16_t)(q[j].hi >> 16);
+                        if (j == 0) xm = (l16 == 0 && t == 0) ? 0.f : xm;  // first sample of the file: history is 0
+                        const float y0 = w0 * (x0 - p.preem * xm);
+                        const float y1 = w1 * (x1 - p.preem * x0);         // w is 0 beyond the window
+                        v[j] = make_float2(y0, y1);
+                        dc += y0 + y1;
                     }
-                    v[j] = make_float2(y0, y1);
-                    dc += y0 + y1;
                 }
 #pragma unroll
                 for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
@@ -197,19 +190,38 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                     dc += __shfl_xor(dc, 4, 64);
                     dc += __shfl_xor(dc, 2, 64);
                     dc += __shfl_xor(dc, 1, 64);
-                    const float m = dc * inv_window;
+                    const float m = dc * p.inv_window;
+                    if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
 #pragma unroll
-                    for (int j = 0; j < NZ; j++) {
-                        const int i0 = 32 * j + 2 * l16;
-                        if (i0 < p.window) v[j].x -= m;
-                        if (i0 + 1 < p.window) v[j].y -= m;
+                        for (int j = 0; j < 16; j++) {
+                            const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
+                            v[j].x -= m * ((j & 1) ? mk.z : mk.x);
+                            v[j].y -= m * ((j & 1) ? mk.w : mk.y);
+                        }
+                    } else {  // exact instantiation: rows < NZ-1 are fully inside the window
+                        const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
+#pragma unroll
+                        for (int j = 0; j < NZ - 1; j++) {
+                            v[j].x -= m;
+                            v[j].y -= m;
+                        }
+                        v[NZ - 1].x -= m * (((NZ - 1) & 1) ? mk.z : mk.x);
+                        v[NZ - 1].y -= m * (((NZ - 1) & 1) ? mk.w : mk.y);
                     }
                 }
 
                 // ---- stage 1: DFT16 over n1 (registers), lane = n2; then twiddle W256^(n2*k1)
+                __builtin_amdgcn_sched_barrier(0);  // keep the twiddle loads below the PCM/window block
+                float4 tw[8];
+#pragma unroll
+                for (int h = 0; h < 8; h++) tw[h] = lc[(LC_TW >> 2) + h];  // (k1 = 2h+1, k1 = 2h+2)
                 dft16(v);
 #pragma unroll
-                for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw[k1]);
+                for (int h = 0; h < 8; h++) {
+                    v[2 * h + 1] = cmul(v[2 * h + 1], make_float2(tw[h].x, tw[h].y));
+                    if (2 * h + 2 < 16) v[2 * h + 2] = cmul(v[2 * h + 2], make_float2(tw[h].z, tw[h].w));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 
                 // ---- transpose [k1][n2] -> lane k1 holds all n2, through LDS, re then im
                 //      element (k1,n2) of frame slot fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1)
@@ -235,6 +247,10 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                 __builtin_amdgcn_wave_barrier();
 
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
+                __builtin_amdgcn_sched_barrier(0);
+                float4 u4[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) u4[h] = lc[(LC_UT >> 2) + h];
                 dft16(v);
 
                 // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
@@ -243,35 +259,38 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                 float *prow = Pt + f * PSTRIDE;
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) {
-                    float br = __shfl(v[15 - k2].x, partner, 64);
-                    float bi = __shfl(v[15 - k2].y, partner, 64);
+                    float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
+                    float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
                     if (l16 == 0) {
                         br = v[(16 - k2) & 15].x;
                         bi = v[(16 - k2) & 15].y;
                     }
+                    const float wr = (k2 & 1) ? u4[k2 >> 1].z : u4[k2 >> 1].x, wi = (k2 & 1) ? u4[k2 >> 1].w : u4[k2 >> 1].y;
                     const float ar = v[k2].x, ai = v[k2].y;
                     const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
-                    const float tr = ut[k2].x * di + ut[k2].y * dr;
-                    const float ti = ut[k2].y * di - ut[k2].x * dr;
+                    const float tr = wr * di + wi * dr;
+                    const float ti = wi * di - wr * dr;
                     const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
-                    float pk = 0.25f * (ur * ur + ui * ui);
-                    float pm = 0.25f * (vr * vr + vi * vi);
+                    const float pk = 0.25f * (ur * ur + ui * ui);
+                    const float pm = 0.25f * (vr * vr + vi * vi);
                     const int k = l16 + 16 * k2;
-                    if (k == 0 && p.remove_dc) pk = 1e-10f;  // src/io/in.cc:390
-                    if (!p.fb_power) {
-                        pk = sqrtf(pk);
-                        pm = sqrtf(pm);
-                    }
                     prow[k] = pk;
                     prow[256 - k] = pm;
                 }
-                if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128])
-                    float p128 = v[8].x * v[8].x + v[8].y * v[8].y;
-                    if (!p.fb_power) p128 = sqrtf(p128);
-                    prow[128] = p128;
+                if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
+                    prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
+                    if (p.remove_dc) prow[0] = 1e-10f;
                 }
             }
             __syncthreads();
+
+            if (!p.fb_power) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
+                for (int e = tid; e < nvalid * 257; e += WG) {
+                    const int f = e / 257, k = e - f * 257;
+                    Pt[f * PSTRIDE + k] = sqrtf(Pt[f * PSTRIDE + k]);
+                }
+                __syncthreads();
+            }
 
             // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
             if (p.nr_exten) {
@@ -300,10 +319,10 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
             // ================= phase 2: lane = frame =================
             const float *prow = Pt + lane * PSTRIDE;
             {
-                const int b0 = p.grp_start[wave], b1 = p.grp_start[wave + 1];
+                const int b0 = grp_start[wave], b1 = grp_start[wave + 1];
                 for (int b = b0; b < b1; b++) {
-                    const int kf = p.band_first[b], len = p.band_len[b];
-                    const float *w = p.fbw + p.band_off[b];
+                    const int kf = band_first[b], len = band_len[b];
+                    const float *w = p.ftab + band_off[b];
                     float acc = 0.f;
                     for (int i = 0; i < len; i += 4) {
                         acc += w[i + 0] * prow[kf + i + 0];
@@ -318,88 +337,103 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
             }
             __syncthreads();
 
+            float *stage = aux + B * 64;  // [64][D] output rows (after the R rows for LPC)
+            int out_w = p.D;
+            float *dst = p.rows;
             if (FEAT == FEAT_SPEC || FEAT == FEAT_LOGSPEC || FEAT == FEAT_LOGMEL_SCRATCH) {
-                float *dst = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.logmel : p.rows;
-                const int width = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.B : p.D;
-                // coalesced copy-out: consecutive threads write consecutive floats of the [nvalid][B] block
-                for (int e = tid; e < nvalid * p.B; e += WG) {
-                    const int f = e / p.B, b = e - f * p.B;
-                    dst[(rbase + f) * width + b] = aux[b * 64 + f];
+                // rows are the band values themselves: coalesced transpose-copy out of aux
+                if (FEAT == FEAT_LOGMEL_SCRATCH) {
+                    dst = p.logmel;
+                    out_w = B;
                 }
-            } else if (FEAT == FEAT_DCTC) {
-                // c_i = sum_b dct[i][b] * logY[b]   (norm and lifter folded into the table)
-                for (int i = wave; i < p.nfea; i += NWAVE) {
-                    const float *d = p.dct + i * p.B;
-                    float c = 0.f;
-                    for (int b = 0; b < p.B; b++) c += d[b] * aux[b * 64 + lane];
-                    const int slot = p.row_slot[i];
-                    if (slot >= 0 && lane < nvalid) p.rows[(rbase + lane) * p.D + slot] = c;
+                for (int e = tid; e < nvalid * B; e += WG) {
+                    const int f = e / B, b = e - f * B;
+                    dst[(rbase + f) * out_w + b] = aux[b * 64 + f];
                 }
-            } else {  // LPC / LPA
-                // autocorrelation by cosine iDFT, k spread over the waves (src/fea/fea_impl.cc:181-198)
-                float *R = aux + p.B * 64;
-                for (int k = wave; k <= p.lporder; k += NWAVE) {
-                    const float *d = p.dct + k * p.B;
-                    float r = 0.f;
-                    for (int b = 0; b < p.B; b++) {
-                        float y = aux[b * 64 + lane];
-                        if (!p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
-                        r += d[b] * y;
+            } else {
+                if (FEAT == FEAT_DCTC) {
+                    // c_i = sum_b dct[i][b] * logY[b]   (norm and lifter folded into the table)
+                    for (int i = wave; i < p.nfea; i += NWAVE) {
+                        const float *d = p.ftab + p.dct_off + i * B;
+                        float c = 0.f;
+                        for (int b = 0; b < B; b++) c += d[b] * aux[b * 64 + lane];
+                        const int slot = row_slot[i];
+                        if (slot >= 0) stage[lane * p.D + slot] = c;
                     }
-                    R[k * 64 + lane] = r;
+                } else {  // LPC / LPA
+                    // autocorrelation by cosine iDFT, k spread over the waves (src/fea/fea_impl.cc:181-198)
+                    float *R = aux + B * 64;
+                    stage = R + (p.lporder + 1) * 64;
+                    for (int k = wave; k <= p.lporder; k += NWAVE) {
+                        const float *d = p.ftab + p.dct_off + k * B;
+                        float r = 0.f;
+                        for (int b = 0; b < B; b++) {
+                            float y = aux[b * 64 + lane];
+                            if (!p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
+                            r += d[b] * y;
+                        }
+                        R[k * 64 + lane] = r;
+                    }
+                    __syncthreads();
+                    if (wave == 0) {
+                        // Levinson-Durbin in double (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
+                        // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
+                        const int P_ = p.lporder;
+                        double a[MAX_LP + 1], c[MAX_LP + 1];
+                        const double r0 = R[lane];
+                        double rc = -(double)R[64 + lane] / r0;
+                        double err = r0 * (1 - rc * rc);
+                        a[0] = 1;
+                        a[1] = rc;
+#pragma unroll
+                        for (int ik = 2; ik <= MAX_LP; ik++) {
+                            if (ik <= P_) {
+                                double dm = R[ik * 64 + lane];
+#pragma unroll
+                                for (int n = 1; n < ik; n++) dm += a[n] * (double)R[(ik - n) * 64 + lane];
+                                rc = -dm / err;
+#pragma unroll
+                                for (int n = 1; n <= ik / 2; n++) {
+                                    const double lo = a[n], hi = a[ik - n];
+                                    a[n] = lo + rc * hi;
+                                    if (n != ik - n) a[ik - n] = hi + rc * lo;
+                                }
+                                a[ik] = rc;
+                                err *= (1 - rc * rc);
+                            }
+                        }
+                        if (FEAT == FEAT_LPA) {
+#pragma unroll
+                            for (int i = 1; i <= MAX_LP; i++)
+                                if (i <= P_) stage[lane * p.D + (i - 1)] = (float)a[i];
+                        } else {
+                            c[0] = log(err);
+#pragma unroll
+                            for (int n = 1; n <= MAX_LP; n++) {
+                                if (n <= p.ncep) {
+                                    double sum = 0;
+#pragma unroll
+                                    for (int k = 1; k < n; k++)
+                                        if (k <= P_) sum += (n - k) * c[n - k] * a[k];
+                                    c[n] = (n <= P_ ? -a[n] : 0.0) - sum / n;
+                                }
+                            }
+#pragma unroll
+                            for (int n = 0; n <= MAX_LP; n++) {
+                                if (n <= p.ncep) {
+                                    double val = c[n];
+                                    if (n >= 1 && p.lifter_on) val *= (double)p.ftab[p.lift_off + n - 1];
+                                    const int slot = row_slot[n];
+                                    if (slot >= 0) stage[lane * p.D + slot] = (float)val;
+                                }
+                            }
+                        }
+                    }
                 }
                 __syncthreads();
-                if (wave == 0) {
-                    // Levinson-Durbin in double (src/fea/fea_impl.cc:200-222), then a -> c (251-284)
-                    const int P_ = p.lporder;
-                    double a[MAX_LP + 1], aa[MAX_LP + 1], c[MAX_LP + 1];
-                    const double r0 = R[lane];
-                    double rc = -(double)R[64 + lane] / r0;
-                    double err = r0 * (1 - rc * rc);
-                    a[0] = aa[0] = 1;
-                    a[1] = aa[1] = rc;
-#pragma unroll
-                    for (int ik = 2; ik <= MAX_LP; ik++) {
-                        if (ik <= P_) {
-                            double dm = R[ik * 64 + lane];
-#pragma unroll
-                            for (int n = 1; n < ik; n++) dm += aa[n] * (double)R[(ik - n) * 64 + lane];
-                            rc = -dm / err;
-                            a[ik] = rc;
-#pragma unroll
-                            for (int n = 1; n < ik; n++) a[n] = aa[n] + rc * aa[ik - n];
-#pragma unroll
-                            for (int n = 1; n <= ik; n++) aa[n] = a[n];
-                            err *= (1 - rc * rc);
-                        }
-                    }
-                    if (FEAT == FEAT_LPA) {
-#pragma unroll
-                        for (int i = 1; i <= MAX_LP; i++)
-                            if (i <= P_ && lane < nvalid) p.rows[(rbase + lane) * p.D + (i - 1)] = (float)a[i];
-                    } else {
-                        c[0] = log(err);
-#pragma unroll
-                        for (int n = 1; n <= MAX_LP; n++) {
-                            if (n <= p.ncep) {
-                                double sum = 0;
-#pragma unroll
-                                for (int k = 1; k < n; k++)
-                                    if (k <= P_) sum += (n - k) * c[n - k] * a[k];
-                                c[n] = (n <= P_ ? -a[n] : 0.0) - sum / n;
-                            }
-                        }
-#pragma unroll
-                        for (int n = 0; n <= MAX_LP; n++) {
-                            if (n <= p.ncep) {
-                                double val = c[n];
-                                if (n >= 1 && p.lifter_on) val *= (double)p.lifter[n - 1];
-                                const int slot = p.row_slot[n];
-                                if (slot >= 0 && lane < nvalid) p.rows[(rbase + lane) * p.D + slot] = (float)val;
-                            }
-                        }
-                    }
-                }
+                // coalesced store of the tile's [nvalid][D] block
+                float *o = p.rows + rbase * p.D;
+                for (int e = tid; e < nvalid * p.D; e += WG) o[e] = stage[e];
             }
             __syncthreads();  // P tile / aux are reused by the next tile
         }
@@ -407,11 +441,11 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
 }
 
 // TRAP-DCT (src/fea/fea_trap.cc:53-127): out[t][b*ndct+k] = sum_j G[k][j] * logmel[clamp(t-half+j)][b]
-// with mean removal, Hamming and REDFT10 folded into G on the host.  One thread per (t, b).
+// with mean removal, Hamming and REDFT10 folded into G on the host (rows of G sum to zero, so the centre
+// frame's value is subtracted first to keep the fp32 accumulation small).  One thread per (t, b).
 __global__ void trapdct_kernel(const float *__restrict__ logmel, float *__restrict__ rows, const float *__restrict__ G,
                                const int4 *__restrict__ utt_info /* {row_off lo, row_off hi, T, -} */, int n_utt, int B,
                                int traplen, int ndct, int D, const int *__restrict__ utt_of_chunk, int chunk) {
-    // grid.x = chunk of frames, threads = chunk*B laid out band-fastest
     const int u = utt_of_chunk[blockIdx.x * 2];
     const int tc = utt_of_chunk[blockIdx.x * 2 + 1];
     const int4 ui = utt_info[u];
@@ -424,10 +458,11 @@ __global__ void trapdct_kernel(const float *__restrict__ logmel, float *__restri
         float acc[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) acc[k] = 0.f;
+        const float xc = logmel[(r0 + t) * B + b];
         for (int j = 0; j < traplen; j++) {
             int s = t - half + j;
             s = s < 0 ? 0 : (s > T - 1 ? T - 1 : s);
-            const float x = logmel[(r0 + s) * B + b];
+            const float x = logmel[(r0 + s) * B + b] - xc;
 #pragma unroll
             for (int k = 0; k < 32; k++)
                 if (k < ndct) acc[k] += G[k * traplen + j] * x;
@@ -483,9 +518,9 @@ struct ctu_engine {
     std::string err;
     int feat = FEAT_DCTC;
     int nz = 16;
-    DevBuf<float> win, fbw, dct, lifter, trapG;
-    DevBuf<float2> tw1, tw2;
-    DevBuf<int> band_first, band_len, band_off, grp_start, row_slot;
+    DevBuf<float> lanec, ftab, trapG;
+    DevBuf<int> itab;
+    int dct_off = 0, lift_off = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
@@ -528,8 +563,10 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.wshift % 2) return "odd frame shift";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
-        if (d.B + o.fea_lporder + 1 > AUX_ROWS) return "filter bank + LP order too large for the LDS staging";
+        if (d.B + o.fea_lporder + 1 + d.D > AUX_ROWS) return "filter bank + LP order too large for the LDS staging";
         if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above the in-register limit";
+    } else if (d.kind == ctu::FeaKind::Dctc) {
+        if (d.B + d.D > AUX_ROWS) return "filter bank + cepstral order too large for the LDS staging";
     } else if (d.B > AUX_ROWS) return "more filter bank channels than the LDS staging holds";
     if (d.kind == ctu::FeaKind::TrapDct && o.fea_trapdct_ndct > 32) return "more than 32 TRAP DCT coefficients";
     return "";
@@ -537,25 +574,33 @@ std::string unsupported_reason(const ctu::Design &d) {
 
 void build_tables(ctu_engine *e) {
     const ctu::Design &d = *e->design;
-    std::vector<float> win(512, 0.f);
-    for (int i = 0; i < d.window; i++) win[i] = (float)d.hamming[i];
-    e->win.upload(win);
     const double pi = 3.14159265358979323846;
-    std::vector<float2> tw1(256), tw2(129);
-    for (int k1 = 0; k1 < 16; k1++)
-        for (int n2 = 0; n2 < 16; n2++) {
-            const double a = -2 * pi * (double)(k1 * n2) / 256.0;
-            tw1[k1 * 16 + n2] = make_float2((float)std::cos(a), (float)std::sin(a));
+    // ---- per-lane constant records (see LC_* above)
+    std::vector<float> lc(16 * LANEC, 0.f);
+    for (int l = 0; l < 16; l++) {
+        float *r = lc.data() + l * LANEC;
+        for (int j = 0; j < 16; j++)
+            for (int h = 0; h < 2; h++) {
+                const int i = 32 * j + 2 * l + h;
+                r[LC_WIN + 2 * j + h] = i < d.window ? (float)d.hamming[i] : 0.f;
+            }
+        for (int j = 0; j < 16; j++)
+            for (int h = 0; h < 2; h++) r[LC_MASK + 2 * j + h] = (32 * j + 2 * l + h) < d.window ? 1.f : 0.f;
+        for (int k1 = 1; k1 < 16; k1++) {
+            const double a = -2 * pi * (double)(k1 * l) / 256.0;
+            r[LC_TW + 2 * (k1 - 1)] = (float)std::cos(a);
+            r[LC_TW + 2 * (k1 - 1) + 1] = (float)std::sin(a);
         }
-    for (int k = 0; k <= 128; k++) {
-        const double a = -2 * pi * (double)k / 512.0;
-        tw2[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        for (int k2 = 0; k2 < 8; k2++) {
+            const double a = -2 * pi * (double)(l + 16 * k2) / 512.0;
+            r[LC_UT + 2 * k2] = (float)std::cos(a);
+            r[LC_UT + 2 * k2 + 1] = (float)std::sin(a);
+        }
     }
-    e->tw1.upload(tw1);
-    e->tw2.upload(tw2);
-    // banded filter bank: per band a run of weights padded to a multiple of 4 bins that stays inside [0,K)
+    e->lanec.upload(lc);
+    // ---- banded filter bank: per band a run of weights padded to a multiple of 4 bins inside [0,K)
     std::vector<int> bf(d.B), bl(d.B), bo(d.B);
-    std::vector<float> w;
+    std::vector<float> ft;
     for (int b = 0; b < d.B; b++) {
         int first = d.fb_first[b], len = d.fb_last[b] - d.fb_first[b] + 1;
         int plen = (len + 3) & ~3;
@@ -563,16 +608,12 @@ void build_tables(ctu_engine *e) {
         if (first < 0) throw std::runtime_error("filter band wider than the spectrum");
         bf[b] = first;
         bl[b] = plen;
-        bo[b] = (int)w.size();
+        bo[b] = (int)ft.size();
         for (int i = 0; i < plen; i++) {
             const int k = first + i;
-            w.push_back((k >= d.fb_first[b] && k <= d.fb_last[b]) ? (float)d.fb[b][k] : 0.f);
+            ft.push_back((k >= d.fb_first[b] && k <= d.fb_last[b]) ? (float)d.fb[b][k] : 0.f);
         }
     }
-    e->band_first.upload(bf);
-    e->band_len.upload(bl);
-    e->band_off.upload(bo);
-    e->fbw.upload(w);
     // contiguous split of the bands over the 8 waves, balanced by (padded) weight count
     std::vector<int> gs(NWAVE + 1, d.B);
     {
@@ -581,23 +622,26 @@ void build_tables(ctu_engine *e) {
         int acc = 0, g = 0;
         gs[0] = 0;
         for (int b = 0; b < d.B; b++) {
-            // start a new group when this band would overshoot the ideal boundary by more than half
             const int cost = bl[b] + 8;
             while (g + 1 < NWAVE && acc + cost / 2 > (int64_t)total * (g + 1) / NWAVE) gs[++g] = b;
             acc += cost;
         }
         while (g + 1 <= NWAVE) gs[++g] = d.B;
     }
-    e->grp_start.upload(gs);
-    std::vector<float> tab;
-    if (d.kind == ctu::FeaKind::Dctc) tab.assign(d.dct.begin(), d.dct.end());
-    else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) tab.assign(d.idft.begin(), d.idft.end());
-    else tab.assign(1, 0.f);
-    e->dct.upload(tab);
-    std::vector<float> lf(d.lifter.begin(), d.lifter.end());
-    if (lf.empty()) lf.push_back(1.f);
-    e->lifter.upload(lf);
-    e->row_slot.upload(d.row_slot);
+    e->dct_off = (int)ft.size();
+    if (d.kind == ctu::FeaKind::Dctc) for (double v : d.dct) ft.push_back((float)v);
+    else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) for (double v : d.idft) ft.push_back((float)v);
+    e->lift_off = (int)ft.size();
+    for (double v : d.lifter) ft.push_back((float)v);
+    ft.push_back(0.f);
+    e->ftab.upload(ft);
+    std::vector<int> it;
+    it.insert(it.end(), bf.begin(), bf.end());
+    it.insert(it.end(), bl.begin(), bl.end());
+    it.insert(it.end(), bo.begin(), bo.end());
+    it.insert(it.end(), gs.begin(), gs.end());
+    it.insert(it.end(), d.row_slot.begin(), d.row_slot.end());
+    e->itab.upload(it);
     if (d.kind == ctu::FeaKind::TrapDct) {
         std::vector<float> g(d.trap.begin(), d.trap.end());
         e->trapG.upload(g);
@@ -772,7 +816,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     pl->row_off.resize(n_utt + 1);
     pl->frames.resize(n_utt);
     const ctu::Design &d = *e->design;
-    int64_t so = 0, ro = 0;
+    int64_t so = PCM_HEAD, ro = 0;
     std::vector<int4> tiles;
     std::vector<int> uts(n_utt + 1, 0);
     std::vector<int4> uinfo(n_utt);
@@ -804,7 +848,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     uts[n_utt] = (int)tiles.size();
     pl->sample_off[n_utt] = so;
     pl->row_off[n_utt] = ro;
-    pl->total_samples = so + PCM_ALIGN;  // tail pad: the last dword of an odd window may straddle the end
+    pl->total_samples = so + PCM_TAIL;  // loads run to the end of the last 32-sample row of a frame
     pl->total_frames = ro;
     pl->n_tiles = (int)tiles.size();
     try {
@@ -854,25 +898,19 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.sample_off = pl->d_sample_off.p;
         kp.row_off = pl->d_row_off.p;
         kp.n_tiles = pl->n_tiles;
-        kp.win = e->win.p;
-        kp.tw1 = e->tw1.p;
-        kp.tw2 = e->tw2.p;
-        kp.band_first = e->band_first.p;
-        kp.band_len = e->band_len.p;
-        kp.band_off = e->band_off.p;
-        kp.fbw = e->fbw.p;
-        kp.grp_start = e->grp_start.p;
-        kp.dct = e->dct.p;
-        kp.lifter = e->lifter.p;
-        kp.row_slot = e->row_slot.p;
-        kp.window = d.window;
+        kp.lanec = e->lanec.p;
+        kp.ftab = e->ftab.p;
+        kp.itab = e->itab.p;
         kp.wshift = d.wshift;
         kp.B = d.B;
         kp.nfea = d.nfea;
         kp.D = d.D;
         kp.ncep = d.o.fea_ncepcoefs;
         kp.lporder = d.o.fea_lporder;
+        kp.dct_off = e->dct_off;
+        kp.lift_off = e->lift_off;
         kp.preem = d.o.preem;
+        kp.inv_window = 1.0f / (float)d.window;
         kp.remove_dc = d.o.remove_dc;
         kp.fb_power = d.o.fb_power;
         kp.fb_inld = d.o.fb_inld;
@@ -920,7 +958,7 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl, const int16_t *h_pcm,
         pcm.alloc((size_t)pl->total_samples);
         rows.alloc((size_t)pl->total_frames * d.D);
         HIP_TRY(hipMemset(pcm.p, 0, (size_t)pl->total_samples * 2));
-        HIP_TRY(hipMemcpy(pcm.p, h_pcm, (size_t)(pl->total_samples - PCM_ALIGN) * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
         int rc = ctu_engine_run(e, pl, pcm.p, rows.p, nullptr, nullptr);
         if (rc != CTU_OK) return rc;
         HIP_TRY(hipDeviceSynchronize());
