@@ -27,7 +27,8 @@ def _deps(dirpath):
 def build_engine(force=False, verbose=False):
     deps = _deps(CSRC) + [os.path.join(ROOT, "include", "ctu_engine.h")]
     if force or _newer(LIB, deps):
-        cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+        # -fno-slp-vectorize: packed f32 VALU (v_pk_*) plus the moves it needs is slower than scalar f32 on gfx950
+        cmd = [HIPCC, "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                *[os.path.join(CSRC, s) for s in ENGINE_SRCS], "-o", LIB]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

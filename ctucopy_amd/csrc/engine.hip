@@ -37,10 +37,9 @@ constexpr int TILE = 64;       // frames per tile (= lanes of the per-frame phas
 constexpr int WG = 512;        // threads per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
 constexpr int PSTRIDE = 257;   // floats per P-tile row (odd: lane-per-frame column reads are conflict-free)
-constexpr int AUX_ROWS = 62;   // [AUX_ROWS][64] floats of per-band / per-coefficient / output staging
-constexpr int LDS_FLOATS = TILE * PSTRIDE + AUX_ROWS * 64;
-static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU need <= 80 KiB each");
+constexpr int LDS_2WG = 80 * 1024;  // two workgroups per CU fit when a workgroup's LDS stays at or under this
 constexpr int MAX_LP = 16;     // Levinson order limit of the in-register recursion
+constexpr int MAXC = 24;       // most coefficients accumulated per frame in phase 2 (cepstra incl. c0, or LP lags)
 constexpr int PCM_ALIGN = 8;   // utterance starts are multiples of this many samples
 constexpr int PCM_HEAD = 8;    // samples of padding before the first utterance (x[-2..-1] of frame 0 is loaded)
 constexpr int PCM_TAIL = 64;   // padding after the last one (loads run to the end of the 32-sample row)
@@ -50,6 +49,9 @@ constexpr int PCM_TAIL = 64;   // padding after the last one (loads run to the e
 // window" pairs for DC removal | [64,96) inter-stage twiddles W256^(l*k1), k1=1..15 (+pad) |
 // [96,112) W512^(l+16*k2), k2=0..7
 constexpr int LC_WIN = 0, LC_MASK = 32, LC_TW = 64, LC_UT = 96, LANEC = 112;
+// The records are copied into LDS per workgroup: PCM streaming keeps evicting them from L1 and a miss costs
+// ~1k cycles.  Row stride 116 floats makes the 16 lanes' ds_read_b128 conflict-free (116 mod 64 = 52).
+constexpr int LTW_STRIDE = 116, LTW_FLOATS = 16 * LTW_STRIDE;
 
 enum FeatMode { FEAT_SPEC = 0, FEAT_LOGSPEC = 1, FEAT_DCTC = 2, FEAT_LPC = 3, FEAT_LPA = 4, FEAT_LOGMEL_SCRATCH = 5 };
 
@@ -57,19 +59,22 @@ struct KParams {
     const int16_t *pcm;
     float *rows;
     float *logmel;              // [total_frames][B] scratch (TRAP only)
-    const int4 *tiles;
-    const int64_t *sample_off;  // per utterance
-    const int64_t *row_off;     // per utterance
-    const int *utt_tile_start;  // [n_utt+1] (by_utt)
+    const struct TileRec *tiles;
+    const int *wg_first;        // [grid] first tile of each workgroup's chain (-1 = none)
     const float *lanec;         // [16][LANEC]
-    const float *ftab;          // band weights at 0, then dct/idft table at dct_off, lifter at lift_off
-    const int *itab;            // band_first[B] | band_len[B] | band_off[B] | grp_start[NWAVE+1] | row_slot[nfea]
-    int n_tiles, n_utt, by_utt;
+    const float *ftab;          // image of the LDS tables (tab_floats), then the lifter at lift_off
+    const int *itab;            // slot_chunk[NS+1] | row_slot[nfea]
+    // LDS tables (float index): chunk weights float4 [NC][8] at 0 | cell {first bin, band index or -1} (int2)
+    // [NS][8] at ck_off | per-cell coefficient rows [NS][8][CW] at cf_off
+    int tab_floats, ck_off, cf_off, NS, CW;
+    int ncoef_out;              // DCTC: coefficients written per row (table rows are in output order)
     int wshift, B, nfea, D, ncep, lporder;
-    int dct_off, lift_off;
+    int lift_off;
     float preem, inv_window;
     int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
     float nr_p, nr_a;
+    unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
+    int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -112,85 +117,211 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k = 0; k < 16; k++) v[k] = t[k];
 }
 
+// Wave-uniform tables are read through constant-address-space pointers so that they become scalar
+// loads (s_load_dword*) into SGPRs instead of per-lane VMEM loads.
+typedef __attribute__((address_space(4))) const float cf32;
+typedef __attribute__((address_space(4))) const int ci32;
+typedef __attribute__((address_space(4))) const int64_t ci64;
+__device__ __forceinline__ cf32 *as_const(const float *p) { return (cf32 *)p; }
+__device__ __forceinline__ ci32 *as_const(const int *p) { return (ci32 *)p; }
+__device__ __forceinline__ ci64 *as_const(const int64_t *p) { return (ci64 *)p; }
+
+// Sum over the 16 lanes of a DPP row, result in every lane: four row-rotate adds on the VALU
+// (no LDS round trips, unlike __shfl_xor which lowers to ds_bpermute).
+__device__ __forceinline__ float row16_allreduce_add(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    return x;
+}
+
+// Sum over 8 consecutive lanes (a frame's band groups), result in all 8: xor-1, xor-2 inside quads, then the
+// mirrored half row brings in the other quad.
+__device__ __forceinline__ float lanes8_allreduce_add(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+    return x;
+}
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
 struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-byte aligned
     uint32_t lo, hi;
 };
 
+// Phase-2 helpers with a compile-time coefficient count (16 or MAXC) so that nothing branches per coefficient.
+template <int NCW>
+__device__ __forceinline__ void cell_accumulate(float (&c)[MAXC], const float4 *cf, float y) {
+    float4 k4[NCW / 4];
+#pragma unroll
+    for (int i = 0; i < NCW / 4; i++) k4[i] = cf[i];  // all loads first, then the FMAs
+#pragma unroll
+    for (int i = 0; i < NCW / 4; i++) {
+        c[4 * i + 0] += k4[i].x * y;
+        c[4 * i + 1] += k4[i].y * y;
+        c[4 * i + 2] += k4[i].z * y;
+        c[4 * i + 3] += k4[i].w * y;
+    }
+}
+template <int NCW>
+__device__ __forceinline__ void cells_reduce(float (&c)[MAXC]) {
+#pragma unroll
+    for (int i = 0; i < NCW; i++) c[i] = lanes8_allreduce_add(c[i]);
+}
+
+// Tile record (32 bytes, read with one scalar load): where the tile's first frame starts in the PCM
+// arena, where its first output row goes, how many of its 64 frame slots are real, the frame index of
+// slot 0 inside its utterance, and the next tile this workgroup walks (-1 = done).
+struct TileRec {
+    int64_t sbase, rbase;
+    int nvalid, t0, next, pad;
+};
+
+__device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
+    ci32 *w = as_const(reinterpret_cast<const int *>(tiles)) + 8 * tile;
+    TileRec r;
+    r.sbase = ((int64_t)w[1] << 32) | (uint32_t)w[0];
+    r.rbase = ((int64_t)w[3] << 32) | (uint32_t)w[2];
+    r.nvalid = w[4];
+    r.t0 = w[5];
+    r.next = w[6];
+    r.pad = 0;
+    return r;
+}
+
 // NZ = number of 32-sample rows that can hold non-zero input (ceil(window/32)); rows >= NZ are
 // literal zeros so the compiler prunes the first butterflies.
+#ifndef CTU_LB
+#define CTU_LB 4        // waves per SIMD the register allocator must leave room for (2 workgroups x 8 waves / 4 SIMDs)
+#endif
+#ifndef CTU_STAMP
+#define CTU_STAMP 0     // diagnostic build: per-wave s_memtime sums per code segment (never in production)
+#endif
+#if CTU_STAMP
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long now_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st_acc[i] += now_ - st_prev;                                                               \
+        st_prev = now_;                                                                            \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#ifndef CTU_LDSDMA
+#define CTU_LDSDMA 1    // second pass's PCM arrives by LDS-DMA during the first pass
+#endif
 template <int NZ, int FEAT>
-__global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
+__global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
-    float *aux = lds + TILE * PSTRIDE;     // [AUX_ROWS][64]
+    float *ltab = lds + TILE * PSTRIDE;    // phase-2 tables (layout: KParams)
+    float *ltw = ltab + p.tab_floats;      // [16][LTW_STRIDE] per-lane constant records
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
     const int fg = lane >> 4;    // frame slot within the wave pass
-    const float4 *lc = reinterpret_cast<const float4 *>(p.lanec + l16 * LANEC);
     const int partner = ((lane & 48) | ((16 - l16) & 15)) << 2;  // byte address for ds_bpermute
-    const int B = p.B;
-    const int *band_first = p.itab, *band_len = p.itab + B, *band_off = p.itab + 2 * B;
-    const int *grp_start = p.itab + 3 * B, *row_slot = p.itab + 3 * B + NWAVE + 1;
+    ci32 *slot_chunk = as_const(p.itab), *row_slot = slot_chunk + p.NS + 1;
+    cf32 *ftab = as_const(p.ftab);
+    for (int i = tid; i < p.tab_floats; i += WG) ltab[i] = p.ftab[i];
+    for (int i = tid; i < 16 * LANEC; i += WG) ltw[(i / LANEC) * LTW_STRIDE + (i % LANEC)] = p.lanec[i];
+    __syncthreads();
+    const float4 *lc = reinterpret_cast<const float4 *>(ltw + l16 * LTW_STRIDE);  // this lane's constant record
+    const float4 *ltw4 = lc + (LC_TW >> 2);                                       // [0,8) stage twiddles, [8,12) untangle
 
+#if CTU_STAMP
+    unsigned long long st_acc[16] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+    int tile = as_const(p.wg_first)[blockIdx.x];
+    if (tile < 0) return;
+    TileRec rec = load_rec(p.tiles, tile);
+
+    // samples x[i0-2 .. i0+1] of row j of frame slot f sit at pcm + sbase + f*wshift + 32 j + 2 l16 - 2
+    auto pcm_ptr = [&](const TileRec &r, int it) {
+        const int f = wave * 8 + it * 4 + fg;
+        const int fc = f < r.nvalid ? f : r.nvalid - 1;  // clamp: duplicates are computed but never stored
+        return p.pcm + r.sbase + (int64_t)fc * p.wshift + 2 * l16 - 2;
+    };
     // exten NR state: thread = bin
     float navg = 0.95f, yavg = 0.05f;
-    int cur_utt = -1;
 
-    const int n_outer = p.by_utt ? p.n_utt : p.n_tiles;
-    for (int outer = blockIdx.x; outer < n_outer; outer += gridDim.x) {
-        int tile_lo = outer, tile_hi = outer + 1;
-        if (p.by_utt) {
-            tile_lo = p.utt_tile_start[outer];
-            tile_hi = p.utt_tile_start[outer + 1];
-        }
-        for (int tile = tile_lo; tile < tile_hi; tile++) {
-            const int4 td = p.tiles[tile];
-            const int utt = td.x, t0 = td.y, nvalid = td.z;
-            const int64_t sbase = p.sample_off[utt];
-            const int64_t rbase = p.row_off[utt] + t0;
+    while (true) {
+        const int nvalid = rec.nvalid;
+        const int64_t rbase = rec.rbase;
+        const int next = rec.next;
+        TileRec nrec = rec;
+        if (next >= 0) nrec = load_rec(p.tiles, next);
+        // this wave owns frame slots [8*wave, 8*wave+8) of the tile and the P rows of the same numbers
+        const int nv = min(max(nvalid - wave * 8, 0), 8);
 
-            // ================= phase 1: frames -> power spectrum rows =================
-            float *scratch = Pt + (wave * 8 + 4) * PSTRIDE;  // this wave's last 4 rows double as transpose scratch
+        // ================= phase 1: frames -> power spectrum rows =================
+        // Pass A (frame slots 0-3 of the wave) loads its PCM from global memory and meanwhile has the PCM of
+        // pass B (slots 4-7) copied by LDS-DMA into the wave's rows 4-7, which nobody needs before pass B
+        // writes its spectra there.  The transpose scratch is rows 0-3 in pass A and rows 4-7 in pass B.
+        constexpr bool DMA = CTU_LDSDMA && (NZ <= 15);  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
+        if (p.dbg != 2 && nv > 0) {
+            const int npass = nv > 4 ? 2 : 1;
 #pragma unroll 1
-            for (int it = 0; it < 2; it++) {
-                const int f = wave * 8 + it * 4 + fg;               // frame slot in tile
-                const int fc = f < nvalid ? f : nvalid - 1;         // clamp (duplicates are never stored)
-                const int t = t0 + fc;
-                // samples x[i0-2 .. i0+1] of row j sit at x + 32 j + 2 l16 - 2 (4-byte aligned)
-                const int16_t *x = p.pcm + sbase + (int64_t)t * p.wshift + 2 * l16 - 2;
-
+            for (int it = 0; it < npass; it++) {
+                const int f = wave * 8 + it * 4 + fg;  // frame slot in tile
+                const bool file_start = (l16 == 0) && (rec.t0 + (f < nvalid ? f : nvalid - 1) == 0);
+                float *scratch = Pt + (wave * 8 + (DMA ? 4 * it : 4)) * PSTRIDE;
+                STAMP(0);  // loop overhead / previous tail
                 float2 v[16];
                 float dc = 0.f;
-                {
-                    pcm4 q[NZ];
+                pcm4 q[NZ];
+                if (!DMA || it == 0) {
+                    const int16_t *x = pcm_ptr(rec, it);
 #pragma unroll
                     for (int j = 0; j < NZ; j++) q[j] = *reinterpret_cast<const pcm4 *>(x + 32 * j);
+                    if (DMA && npass == 2) {
+                        const int cl = lane < (32 * NZ + 8) / 8 ? lane : (32 * NZ + 8) / 8 - 1;  // 8-sample chunks of a frame
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int fb = wave * 8 + 4 + k;
+                            const int16_t *src = p.pcm + rec.sbase + (int64_t)(fb < nvalid ? fb : nvalid - 1) * p.wshift - 8 + 8 * cl;
+                            __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)(Pt + (wave * 8 + 4) * PSTRIDE + 256 * k), 16, 0, 0);
+                        }
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA issued in pass A has landed
+                    const uint32_t *lp = reinterpret_cast<const uint32_t *>(Pt + (wave * 8 + 4) * PSTRIDE + 256 * fg) + 3 + l16;
 #pragma unroll
                     for (int j = 0; j < NZ; j++) {
-                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
-                        const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
-                        float xm = (float)(int16_t)(q[j].lo >> 16);
-                        const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
-                        const float x1 = (float)(int16_t)(q[j].hi >> 16);
-                        if (j == 0) xm = (l16 == 0 && t == 0) ? 0.f : xm;  // first sample of the file: history is 0
-                        const float y0 = w0 * (x0 - p.preem * xm);
-                        const float y1 = w1 * (x1 - p.preem * x0);         // w is 0 beyond the window
-                        v[j] = make_float2(y0, y1);
-                        dc += y0 + y1;
+                        q[j].lo = lp[16 * j];
+                        q[j].hi = lp[16 * j + 1];
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int j = 0; j < NZ; j++) {
+                    const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
+                    const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
+                    float xm = (float)(int16_t)(q[j].lo >> 16);
+                    const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
+                    const float x1 = (float)(int16_t)(q[j].hi >> 16);
+                    if (j == 0) xm = file_start ? 0.f : xm;  // first sample of the file: history is 0
+                    const float y0 = w0 * (x0 - p.preem * xm);
+                    const float y1 = w1 * (x1 - p.preem * x0);  // w is 0 beyond the window
+                    v[j] = make_float2(y0, y1);
+                    dc += y0 + y1;
                 }
 #pragma unroll
                 for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
+                STAMP(1);  // PCM + window loads, convert, pre-emphasis, window
                 if (p.remove_dc) {
                     // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
-                    dc += __shfl_xor(dc, 8, 64);
-                    dc += __shfl_xor(dc, 4, 64);
-                    dc += __shfl_xor(dc, 2, 64);
-                    dc += __shfl_xor(dc, 1, 64);
-                    const float m = dc * p.inv_window;
+                    const float m = row16_allreduce_add(dc) * p.inv_window;
                     if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
 #pragma unroll
                         for (int j = 0; j < 16; j++) {
@@ -210,19 +341,18 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                     }
                 }
 
+                STAMP(2);  // DC removal
                 // ---- stage 1: DFT16 over n1 (registers), lane = n2; then twiddle W256^(n2*k1)
-                __builtin_amdgcn_sched_barrier(0);  // keep the twiddle loads below the PCM/window block
-                float4 tw[8];
-#pragma unroll
-                for (int h = 0; h < 8; h++) tw[h] = lc[(LC_TW >> 2) + h];  // (k1 = 2h+1, k1 = 2h+2)
                 dft16(v);
+                __builtin_amdgcn_sched_barrier(0);  // twiddles are L1 hits: fetch them just in time, not across the DFT
 #pragma unroll
                 for (int h = 0; h < 8; h++) {
-                    v[2 * h + 1] = cmul(v[2 * h + 1], make_float2(tw[h].x, tw[h].y));
-                    if (2 * h + 2 < 16) v[2 * h + 2] = cmul(v[2 * h + 2], make_float2(tw[h].z, tw[h].w));
+                    const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
+                    v[2 * h + 1] = cmul(v[2 * h + 1], make_float2(tw.x, tw.y));
+                    if (2 * h + 2 < 16) v[2 * h + 2] = cmul(v[2 * h + 2], make_float2(tw.z, tw.w));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-
+                STAMP(3);  // DFT16 #1 + twiddles
                 // ---- transpose [k1][n2] -> lane k1 holds all n2, through LDS, re then im
                 //      element (k1,n2) of frame slot fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1)
                 const int sw = fg * 256;
@@ -246,12 +376,10 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 
+                STAMP(4);  // LDS transpose
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
-                __builtin_amdgcn_sched_barrier(0);
-                float4 u4[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) u4[h] = lc[(LC_UT >> 2) + h];
                 dft16(v);
+                STAMP(5);  // DFT16 #2
 
                 // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
                 //      each together with its mirror bin 256-k held by lane (16-k1)%16 in register 15-k2
@@ -259,13 +387,15 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                 float *prow = Pt + f * PSTRIDE;
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) {
+                    if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // two batches: bounds the registers in flight
+                    const float4 u4q = ltw4[8 + (k2 >> 1)];
                     float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
                     float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
                     if (l16 == 0) {
                         br = v[(16 - k2) & 15].x;
                         bi = v[(16 - k2) & 15].y;
                     }
-                    const float wr = (k2 & 1) ? u4[k2 >> 1].z : u4[k2 >> 1].x, wi = (k2 & 1) ? u4[k2 >> 1].w : u4[k2 >> 1].y;
+                    const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
                     const float ar = v[k2].x, ai = v[k2].y;
                     const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
                     const float tr = wr * di + wi * dr;
@@ -281,163 +411,199 @@ __global__ __launch_bounds__(WG, 4) void frontend_kernel(const KParams p) {
                     prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
                     if (p.remove_dc) prow[0] = 1e-10f;
                 }
+                STAMP(6);  // untangle + P writes
             }
-            __syncthreads();
-
-            if (!p.fb_power) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
-                for (int e = tid; e < nvalid * 257; e += WG) {
-                    const int f = e / 257, k = e - f * 257;
-                    Pt[f * PSTRIDE + k] = sqrtf(Pt[f * PSTRIDE + k]);
-                }
-                __syncthreads();
-            }
-
-            // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
-            if (p.nr_exten) {
-                if (utt != cur_utt) {  // new file: Navg = 0.95, Yavg = 0.05
-                    navg = 0.95f;
-                    yavg = 0.05f;
-                    cur_utt = utt;
-                }
-                if (tid < 257) {
-                    const float pp = p.nr_p, qq = 1.0f - p.nr_p;
-                    for (int f = 0; f < nvalid; f++) {
-                        const float X = Pt[f * PSTRIDE + tid];
-                        float H;
-                        if (p.nr_a == 1.0f) H = navg / (navg + yavg);
-                        else if (p.nr_a == 2.0f) H = navg / sqrtf(navg * navg + yavg * yavg);
-                        else H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
-                        const float N = H * X;
-                        navg = pp * navg + qq * N;
-                        yavg = fabsf(X - navg);
-                        Pt[f * PSTRIDE + tid] = X - N;
-                    }
-                }
-                __syncthreads();
-            }
-
-            // ================= phase 2: lane = frame =================
-            const float *prow = Pt + lane * PSTRIDE;
-            {
-                const int b0 = grp_start[wave], b1 = grp_start[wave + 1];
-                for (int b = b0; b < b1; b++) {
-                    const int kf = band_first[b], len = band_len[b];
-                    const float *w = p.ftab + band_off[b];
-                    float acc = 0.f;
-                    for (int i = 0; i < len; i += 4) {
-                        acc += w[i + 0] * prow[kf + i + 0];
-                        acc += w[i + 1] * prow[kf + i + 1];
-                        acc += w[i + 2] * prow[kf + i + 2];
-                        acc += w[i + 3] * prow[kf + i + 3];
-                    }
-                    if (p.fb_inld) acc = __powf(acc, 0.33f);  // src/fea/fb.cc:81-83
-                    if (FEAT == FEAT_LOGSPEC || FEAT == FEAT_DCTC || FEAT == FEAT_LOGMEL_SCRATCH) acc = __logf(acc);
-                    aux[b * 64 + lane] = acc;
-                }
-            }
-            __syncthreads();
-
-            float *stage = aux + B * 64;  // [64][D] output rows (after the R rows for LPC)
-            int out_w = p.D;
-            float *dst = p.rows;
-            if (FEAT == FEAT_SPEC || FEAT == FEAT_LOGSPEC || FEAT == FEAT_LOGMEL_SCRATCH) {
-                // rows are the band values themselves: coalesced transpose-copy out of aux
-                if (FEAT == FEAT_LOGMEL_SCRATCH) {
-                    dst = p.logmel;
-                    out_w = B;
-                }
-                for (int e = tid; e < nvalid * B; e += WG) {
-                    const int f = e / B, b = e - f * B;
-                    dst[(rbase + f) * out_w + b] = aux[b * 64 + f];
-                }
-            } else {
-                if (FEAT == FEAT_DCTC) {
-                    // c_i = sum_b dct[i][b] * logY[b]   (norm and lifter folded into the table)
-                    for (int i = wave; i < p.nfea; i += NWAVE) {
-                        const float *d = p.ftab + p.dct_off + i * B;
-                        float c = 0.f;
-                        for (int b = 0; b < B; b++) c += d[b] * aux[b * 64 + lane];
-                        const int slot = row_slot[i];
-                        if (slot >= 0) stage[lane * p.D + slot] = c;
-                    }
-                } else {  // LPC / LPA
-                    // autocorrelation by cosine iDFT, k spread over the waves (src/fea/fea_impl.cc:181-198)
-                    float *R = aux + B * 64;
-                    stage = R + (p.lporder + 1) * 64;
-                    for (int k = wave; k <= p.lporder; k += NWAVE) {
-                        const float *d = p.ftab + p.dct_off + k * B;
-                        float r = 0.f;
-                        for (int b = 0; b < B; b++) {
-                            float y = aux[b * 64 + lane];
-                            if (!p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
-                            r += d[b] * y;
-                        }
-                        R[k * 64 + lane] = r;
-                    }
-                    __syncthreads();
-                    if (wave == 0) {
-                        // Levinson-Durbin in double (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
-                        // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
-                        const int P_ = p.lporder;
-                        double a[MAX_LP + 1], c[MAX_LP + 1];
-                        const double r0 = R[lane];
-                        double rc = -(double)R[64 + lane] / r0;
-                        double err = r0 * (1 - rc * rc);
-                        a[0] = 1;
-                        a[1] = rc;
-#pragma unroll
-                        for (int ik = 2; ik <= MAX_LP; ik++) {
-                            if (ik <= P_) {
-                                double dm = R[ik * 64 + lane];
-#pragma unroll
-                                for (int n = 1; n < ik; n++) dm += a[n] * (double)R[(ik - n) * 64 + lane];
-                                rc = -dm / err;
-#pragma unroll
-                                for (int n = 1; n <= ik / 2; n++) {
-                                    const double lo = a[n], hi = a[ik - n];
-                                    a[n] = lo + rc * hi;
-                                    if (n != ik - n) a[ik - n] = hi + rc * lo;
-                                }
-                                a[ik] = rc;
-                                err *= (1 - rc * rc);
-                            }
-                        }
-                        if (FEAT == FEAT_LPA) {
-#pragma unroll
-                            for (int i = 1; i <= MAX_LP; i++)
-                                if (i <= P_) stage[lane * p.D + (i - 1)] = (float)a[i];
-                        } else {
-                            c[0] = log(err);
-#pragma unroll
-                            for (int n = 1; n <= MAX_LP; n++) {
-                                if (n <= p.ncep) {
-                                    double sum = 0;
-#pragma unroll
-                                    for (int k = 1; k < n; k++)
-                                        if (k <= P_) sum += (n - k) * c[n - k] * a[k];
-                                    c[n] = (n <= P_ ? -a[n] : 0.0) - sum / n;
-                                }
-                            }
-#pragma unroll
-                            for (int n = 0; n <= MAX_LP; n++) {
-                                if (n <= p.ncep) {
-                                    double val = c[n];
-                                    if (n >= 1 && p.lifter_on) val *= (double)p.ftab[p.lift_off + n - 1];
-                                    const int slot = row_slot[n];
-                                    if (slot >= 0) stage[lane * p.D + slot] = (float)val;
-                                }
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                // coalesced store of the tile's [nvalid][D] block
-                float *o = p.rows + rbase * p.D;
-                for (int e = tid; e < nvalid * p.D; e += WG) o[e] = stage[e];
-            }
-            __syncthreads();  // P tile / aux are reused by the next tile
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        if (!p.fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
+            for (int e = lane; e < nv * 257; e += 64) {
+                const int f = e / 257, k = e - f * 257;
+                float *q_ = Pt + (wave * 8 + f) * PSTRIDE + k;
+                *q_ = sqrtf(*q_);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
+        // The only cross-wave step: one lane per bin walks the tile's frames in order (workgroup barriers).
+        if (p.nr_exten) {
+            __syncthreads();
+            if (rec.t0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
+                navg = 0.95f;
+                yavg = 0.05f;
+            }
+            if (tid < 257) {
+                const float pp = p.nr_p, qq = 1.0f - p.nr_p;
+                for (int f = 0; f < nvalid; f++) {
+                    const float X = Pt[f * PSTRIDE + tid];
+                    float H;
+                    if (p.nr_a == 1.0f) H = navg / (navg + yavg);
+                    else if (p.nr_a == 2.0f) H = navg / sqrtf(navg * navg + yavg * yavg);
+                    else H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
+                    const float N = H * X;
+                    navg = pp * navg + qq * N;
+                    yavg = fabsf(X - navg);
+                    Pt[f * PSTRIDE + tid] = X - N;
+                }
+            }
+            __syncthreads();
+        }
+        STAMP(7);  // hand-over to phase 2 (incl. NR)
+
+        // ================= phase 2 (wave-local): lane = (frame, band group) =================
+        // The wave's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
+        // 8 bands of a slot have similar widths; every group walks the same number of 4-bin chunks per slot.
+        if (p.dbg != 1 && nv > 0) {
+            const int f8 = lane >> 3, g = lane & 7;
+            const int fslot = wave * 8 + f8;
+            const bool fvalid = f8 < nv;
+            const float *prow2 = Pt + fslot * PSTRIDE;
+            float c[MAXC];
+#pragma unroll
+            for (int i = 0; i < MAXC; i++) c[i] = 0.f;
+            for (int sl = 0; sl < p.NS; sl++) {
+                const int cb = slot_chunk[sl], ce = slot_chunk[sl + 1];
+                // {first bin of the cell's chunk run, band index or -1}: the only per-lane indirection of the slot
+                const int kstart = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2]);
+                const int bidx = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2 + 1]);
+                const float *pr = prow2 + kstart;
+                const float4 *wq = reinterpret_cast<const float4 *>(ltab) + cb * 8 + g;
+                float acc = 0.f, acc1 = 0.f;
+                const int nch = ce - cb;
+                int ch = 0;
+                for (; ch + 4 <= nch; ch += 4) {  // 4 chunks per group: 12 LDS reads in flight, then 16 FMAs
+                    float4 w4[4];
+                    float pv[16];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) w4[u] = wq[(ch + u) * 8];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) pv[i] = pr[4 * ch + i];
+#pragma unroll
+                    for (int u = 0; u < 4; u += 2) {
+                        acc += w4[u].x * pv[4 * u + 0];
+                        acc1 += w4[u + 1].x * pv[4 * u + 4];
+                        acc += w4[u].y * pv[4 * u + 1];
+                        acc1 += w4[u + 1].y * pv[4 * u + 5];
+                        acc += w4[u].z * pv[4 * u + 2];
+                        acc1 += w4[u + 1].z * pv[4 * u + 6];
+                        acc += w4[u].w * pv[4 * u + 3];
+                        acc1 += w4[u + 1].w * pv[4 * u + 7];
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU
+                }
+                for (; ch < nch; ch++) {
+                    const float4 w4 = wq[ch * 8];
+                    const float p0 = pr[4 * ch + 0], p1 = pr[4 * ch + 1], p2 = pr[4 * ch + 2], p3 = pr[4 * ch + 3];
+                    acc += w4.x * p0;
+                    acc1 += w4.y * p1;
+                    acc += w4.z * p2;
+                    acc1 += w4.w * p3;
+                }
+                acc += acc1;
+                float y = acc;
+                if (p.fb_inld) y = __powf(y, 0.33f);  // src/fea/fb.cc:81-83
+                if (FEAT == FEAT_LOGSPEC || FEAT == FEAT_DCTC || FEAT == FEAT_LOGMEL_SCRATCH) y = __logf(y);
+                if (FEAT == FEAT_SPEC || FEAT == FEAT_LOGSPEC || FEAT == FEAT_LOGMEL_SCRATCH) {
+                    float *dst = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.logmel : p.rows;
+                    const int out_w = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.B : p.D;
+                    if (bidx >= 0 && fvalid) dst[(rbase + fslot) * out_w + bidx] = y;
+                } else {
+                    if ((FEAT == FEAT_LPC || FEAT == FEAT_LPA) && !p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
+                    y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
+                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * p.CW);
+                    if (p.CW == 16) cell_accumulate<16>(c, cf, y);
+                    else cell_accumulate<MAXC>(c, cf, y);
+                }
+            }
+            STAMP(8);  // filter bank + per-band accumulation
+            if (FEAT == FEAT_DCTC || FEAT == FEAT_LPC || FEAT == FEAT_LPA) {
+                if (p.CW == 16) cells_reduce<16>(c);
+                else cells_reduce<MAXC>(c);
+                float *orow = p.rows + (rbase + fslot) * p.D;
+                if (FEAT == FEAT_DCTC) {
+                    // c[r] = value of output slot r = sum_b dct[i(r)][b] * logY[b]  (norm, lifter and the writer's
+                    // c1..cN,c0 order are folded into the table on the host); lane g stores slots g, g+8, g+16
+#pragma unroll
+                    for (int h = 0; h < MAXC / 8; h++) {
+                        if (h * 8 < p.ncoef_out) {
+                            float val = c[h * 8];
+#pragma unroll
+                            for (int j = 1; j < 8; j++) val = (g == j) ? c[h * 8 + j] : val;
+                            if (fvalid && h * 8 + g < p.ncoef_out) orow[h * 8 + g] = val;
+                        }
+                    }
+                } else {
+                    // c[k] = R[k], the autocorrelation by cosine iDFT (src/fea/fea_impl.cc:181-198); every lane of the
+                    // frame runs Levinson-Durbin in double (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
+                    // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
+                    const int P_ = p.lporder;
+                    double a[MAX_LP + 1], cc[MAX_LP + 1];
+                    const double r0 = c[0];
+                    double rc = -(double)c[1] / r0;
+                    double err = r0 * (1 - rc * rc);
+                    a[0] = 1;
+                    a[1] = rc;
+#pragma unroll
+                    for (int ik = 2; ik <= MAX_LP; ik++) {
+                        if (ik <= P_) {
+                            double dm = c[ik];
+#pragma unroll
+                            for (int n = 1; n < ik; n++) dm += a[n] * (double)c[ik - n];
+                            rc = -dm / err;
+#pragma unroll
+                            for (int n = 1; n <= ik / 2; n++) {
+                                const double lo = a[n], hi = a[ik - n];
+                                a[n] = lo + rc * hi;
+                                if (n != ik - n) a[ik - n] = hi + rc * lo;
+                            }
+                            a[ik] = rc;
+                            err *= (1 - rc * rc);
+                        }
+                    }
+                    if (FEAT == FEAT_LPA) {
+#pragma unroll
+                        for (int i = 1; i <= MAX_LP; i++)
+                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = (float)a[i];
+                    } else {
+                        cc[0] = log(err);
+#pragma unroll
+                        for (int n = 1; n <= MAX_LP; n++) {
+                            if (n <= p.ncep) {
+                                double sum = 0;
+#pragma unroll
+                                for (int k = 1; k < n; k++)
+                                    if (k <= P_) sum += (n - k) * cc[n - k] * a[k];
+                                cc[n] = (n <= P_ ? -a[n] : 0.0) - sum / n;
+                            }
+                        }
+#pragma unroll
+                        for (int n = 0; n <= MAX_LP; n++) {
+                            if (n <= p.ncep) {
+                                double val = cc[n];
+                                if (n >= 1 && p.lifter_on) val *= (double)ftab[p.lift_off + n - 1];
+                                const int slot = row_slot[n];
+                                if (slot >= 0 && fvalid && g == (n & 7)) orow[slot] = (float)val;
+                            }
+                        }
+                    }
+                }
+            }
+            STAMP(10);  // reduction, tail, row store
+        }
+        if (p.nr_exten) __syncthreads();  // the bin-wise NR pass of the next tile reads every wave's rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (next < 0) break;
+        rec = nrec;
     }
+#if CTU_STAMP
+    if (lane == 0 && p.stamps)
+        for (int i = 0; i < 16; i++) p.stamps[(blockIdx.x * NWAVE + wave) * 16 + i] = st_acc[i];
+#endif
 }
 
 // TRAP-DCT (src/fea/fea_trap.cc:53-127): out[t][b*ndct+k] = sum_j G[k][j] * logmel[clamp(t-half+j)][b]
@@ -520,10 +686,12 @@ struct ctu_engine {
     int nz = 16;
     DevBuf<float> lanec, ftab, trapG;
     DevBuf<int> itab;
-    int dct_off = 0, lift_off = 0;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
+    DevBuf<unsigned long long> stamps;
 };
 
 struct ctu_plan {
@@ -532,9 +700,9 @@ struct ctu_plan {
     std::vector<int64_t> nsamples, sample_off, row_off, frames;
     int64_t total_samples = 0, total_frames = 0;
     int n_tiles = 0;
-    DevBuf<int4> tiles;
-    DevBuf<int64_t> d_sample_off, d_row_off;
-    DevBuf<int> utt_tile_start;
+    int grid = 0;               // workgroups of the front-end launch (tile chains are built for it)
+    DevBuf<TileRec> tiles;
+    DevBuf<int> wg_first;
     // TRAP
     DevBuf<int4> utt_info;
     DevBuf<int> trap_chunks;
@@ -560,14 +728,13 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.fea_E) return "-fea_E on";
     if (o.do_vad()) return "VAD module";
     if (d.wfft != 512) return "FFT size other than 512";
-    if (d.wshift % 2) return "odd frame shift";
+    if (d.wshift % 8) return "frame shift that is not a multiple of 8 samples (16-byte aligned frame starts)";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
-        if (d.B + o.fea_lporder + 1 + d.D > AUX_ROWS) return "filter bank + LP order too large for the LDS staging";
         if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above the in-register limit";
-    } else if (d.kind == ctu::FeaKind::Dctc) {
-        if (d.B + d.D > AUX_ROWS) return "filter bank + cepstral order too large for the LDS staging";
-    } else if (d.B > AUX_ROWS) return "more filter bank channels than the LDS staging holds";
+    }
+    if (d.kind == ctu::FeaKind::Dctc && d.nfea > MAXC) return "more cepstral coefficients than the kernel accumulates";
+    if (d.B > 512) return "more than 512 filter bank channels";
     if (d.kind == ctu::FeaKind::TrapDct && o.fea_trapdct_ndct > 32) return "more than 32 TRAP DCT coefficients";
     return "";
 }
@@ -598,50 +765,93 @@ void build_tables(ctu_engine *e) {
         }
     }
     e->lanec.upload(lc);
-    // ---- banded filter bank: per band a run of weights padded to a multiple of 4 bins inside [0,K)
-    std::vector<int> bf(d.B), bl(d.B), bo(d.B);
-    std::vector<float> ft;
-    for (int b = 0; b < d.B; b++) {
-        int first = d.fb_first[b], len = d.fb_last[b] - d.fb_first[b] + 1;
-        int plen = (len + 3) & ~3;
-        if (first + plen > d.K) first = d.K - plen;
-        if (first < 0) throw std::runtime_error("filter band wider than the spectrum");
-        bf[b] = first;
-        bl[b] = plen;
-        bo[b] = (int)ft.size();
-        for (int i = 0; i < plen; i++) {
-            const int k = first + i;
-            ft.push_back((k >= d.fb_first[b] && k <= d.fb_last[b]) ? (float)d.fb[b][k] : 0.f);
-        }
+    // ---- phase-2 tables.  Bands are dealt to (slot, group) cells: sorted by width, eight per slot, so that the
+    // eight lanes of a frame walk bands of similar width in lock step.  A band is cut into 4-bin chunks whose
+    // bin range stays inside [0,K); weights outside the band's own [first,last] are zero.
+    const int B = d.B, K = d.K;
+    std::vector<int> order(B);
+    for (int b = 0; b < B; b++) order[b] = b;
+    auto width = [&](int b) { return d.fb_last[b] - d.fb_first[b] + 1; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return width(x) > width(y); });
+    const int NS = (B + 7) / 8;
+    int ncoef = 0;
+    const std::vector<double> *coef_tab = nullptr;
+    if (d.kind == ctu::FeaKind::Dctc) { coef_tab = &d.dct; ncoef = d.nfea; }
+    else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) { coef_tab = &d.idft; ncoef = d.o.fea_lporder + 1; }
+    if (ncoef > MAXC) throw std::runtime_error("more cepstral / LP coefficients than the kernel accumulates");
+    const int CW = ncoef <= 16 ? 16 : MAXC;  // the kernel has straight-line code for these two widths
+    std::vector<int> slot_chunk(NS + 1, 0);
+    std::vector<float> cw;                  // chunk weights [NC][8][4]
+    std::vector<int> cell(NS * 8 * 2, 0);   // {first bin of the chunk run, band index or -1}
+    std::vector<float> cf((size_t)NS * 8 * CW, 0.f);
+    // DCTC: coefficient row r of a cell is the value written to output slot r (c1..cN, then c0)
+    std::vector<int> coef_of_slot;
+    if (d.kind == ctu::FeaKind::Dctc) {
+        coef_of_slot.assign(d.nfea, -1);
+        int nout = 0;
+        for (int i = 0; i < d.nfea; i++)
+            if (d.row_slot[i] >= 0) {
+                coef_of_slot[d.row_slot[i]] = i;
+                nout = std::max(nout, d.row_slot[i] + 1);
+            }
+        e->ncoef_out = nout;
     }
-    // contiguous split of the bands over the 8 waves, balanced by (padded) weight count
-    std::vector<int> gs(NWAVE + 1, d.B);
-    {
-        int total = 0;
-        for (int b = 0; b < d.B; b++) total += bl[b] + 8;
-        int acc = 0, g = 0;
-        gs[0] = 0;
-        for (int b = 0; b < d.B; b++) {
-            const int cost = bl[b] + 8;
-            while (g + 1 < NWAVE && acc + cost / 2 > (int64_t)total * (g + 1) / NWAVE) gs[++g] = b;
-            acc += cost;
+    for (int sl = 0; sl < NS; sl++) {
+        int nch = 0;
+        for (int g = 0; g < 8 && sl * 8 + g < B; g++) nch = std::max(nch, (width(order[sl * 8 + g]) + 3) / 4);
+        if (4 * nch > K) throw std::runtime_error("filter band wider than the spectrum");
+        slot_chunk[sl] = (int)cw.size() / 32;
+        std::vector<int> kstart(8, 0);
+        for (int g = 0; g < 8; g++) {
+            cell[(sl * 8 + g) * 2 + 1] = -1;
+            if (sl * 8 + g >= B) continue;
+            const int b = order[sl * 8 + g];
+            kstart[g] = std::min(d.fb_first[b], K - 4 * nch);  // the run of nch chunks must end inside the row
+            cell[(sl * 8 + g) * 2] = kstart[g];
+            cell[(sl * 8 + g) * 2 + 1] = b;
+            for (int i = 0; i < ncoef; i++) {
+                const int src = (d.kind == ctu::FeaKind::Dctc) ? coef_of_slot[i] : i;
+                if (src >= 0) cf[((size_t)sl * 8 + g) * CW + i] = (float)(*coef_tab)[(size_t)src * B + b];
+            }
         }
-        while (g + 1 <= NWAVE) gs[++g] = d.B;
+        for (int ch = 0; ch < nch; ch++)
+            for (int g = 0; g < 8; g++)
+                for (int i = 0; i < 4; i++) {
+                    float w = 0.f;
+                    if (sl * 8 + g < B) {
+                        const int b = order[sl * 8 + g], k = kstart[g] + 4 * ch + i;
+                        if (k >= d.fb_first[b] && k <= d.fb_last[b]) w = (float)d.fb[b][k];
+                    }
+                    cw.push_back(w);
+                }
     }
-    e->dct_off = (int)ft.size();
-    if (d.kind == ctu::FeaKind::Dctc) for (double v : d.dct) ft.push_back((float)v);
-    else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) for (double v : d.idft) ft.push_back((float)v);
+    slot_chunk[NS] = (int)cw.size() / 32;
+    std::vector<float> ft(cw);
+    auto push_ints = [&](const std::vector<int> &v) {
+        for (int x : v) {
+            float f;
+            std::memcpy(&f, &x, 4);
+            ft.push_back(f);
+        }
+        while (ft.size() & 3) ft.push_back(0.f);
+    };
+    e->ck_off = (int)ft.size();
+    push_ints(cell);
+    e->cf_off = (int)ft.size();
+    ft.insert(ft.end(), cf.begin(), cf.end());
+    while (ft.size() & 3) ft.push_back(0.f);
+    e->tab_floats = (int)ft.size();
+    e->NS = NS;
+    e->CW = CW;
     e->lift_off = (int)ft.size();
     for (double v : d.lifter) ft.push_back((float)v);
     ft.push_back(0.f);
     e->ftab.upload(ft);
-    std::vector<int> it;
-    it.insert(it.end(), bf.begin(), bf.end());
-    it.insert(it.end(), bl.begin(), bl.end());
-    it.insert(it.end(), bo.begin(), bo.end());
-    it.insert(it.end(), gs.begin(), gs.end());
+    std::vector<int> it(slot_chunk);
     it.insert(it.end(), d.row_slot.begin(), d.row_slot.end());
     e->itab.upload(it);
+    e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS) * sizeof(float);
+    if (e->lds_bytes > 160 * 1024) throw std::runtime_error("configuration needs more than 160 KiB of LDS");
     if (d.kind == ctu::FeaKind::TrapDct) {
         std::vector<float> g(d.trap.begin(), d.trap.end());
         e->trapG.upload(g);
@@ -658,14 +868,13 @@ void build_tables(ctu_engine *e) {
 }
 
 template <int NZ>
-void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp) {
-    const size_t shm = LDS_FLOATS * sizeof(float);
+void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
 #define LAUNCH(F)                                                                                      \
     case F: {                                                                                          \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F>),       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));        \
             attr_set = true;                                                                           \
         }                                                                                              \
         hipLaunchKernelGGL((frontend_kernel<NZ, F>), grid, dim3(WG), shm, s, kp);                      \
@@ -817,7 +1026,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     pl->frames.resize(n_utt);
     const ctu::Design &d = *e->design;
     int64_t so = PCM_HEAD, ro = 0;
-    std::vector<int4> tiles;
+    std::vector<TileRec> tiles;
     std::vector<int> uts(n_utt + 1, 0);
     std::vector<int4> uinfo(n_utt);
     std::vector<int> chunks;
@@ -836,7 +1045,16 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
         pl->row_off[i] = ro;
         pl->frames[i] = T;
         uts[i] = (int)tiles.size();
-        for (int64_t t0 = 0; t0 < T; t0 += TILE) tiles.push_back(make_int4(i, (int)t0, (int)std::min<int64_t>(TILE, T - t0), 0));
+        for (int64_t t0 = 0; t0 < T; t0 += TILE) {
+            TileRec r;
+            r.sbase = so + t0 * d.wshift;
+            r.rbase = ro + t0;
+            r.nvalid = (int)std::min<int64_t>(TILE, T - t0);
+            r.t0 = (int)t0;
+            r.next = -1;
+            r.pad = 0;
+            tiles.push_back(r);
+        }
         uinfo[i] = make_int4((int)(ro & 0xffffffff), (int)(ro >> 32), (int)T, 0);
         for (int64_t tc = 0; tc < T; tc += trap_chunk) {
             chunks.push_back(i);
@@ -851,12 +1069,34 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     pl->total_samples = so + PCM_TAIL;  // loads run to the end of the last 32-sample row of a frame
     pl->total_frames = ro;
     pl->n_tiles = (int)tiles.size();
+    // Each workgroup walks a chain of tiles.  Stateless chains stride over the tile list; with a
+    // per-utterance recurrence (exten) a workgroup takes whole utterances, tile after tile.
+    std::vector<int> wg_first;
+    const int max_wg = e->n_cu * ((CTU_LB >= 4 && e->lds_bytes <= (size_t)LDS_2WG) ? 2 : 1);
+    if (d.o.nr_mode == "exten") {
+        std::vector<int> live;  // utterances that have at least one frame
+        for (int i = 0; i < n_utt; i++)
+            if (uts[i + 1] > uts[i]) live.push_back(i);
+        const int G = std::max(1, std::min<int>((int)live.size(), max_wg));
+        wg_first.assign(G, -1);
+        for (size_t k = 0; k < live.size(); k++) {
+            const int u = live[k];
+            for (int t = uts[u]; t + 1 < uts[u + 1]; t++) tiles[t].next = t + 1;
+            tiles[uts[u + 1] - 1].next = (k + G < live.size()) ? uts[live[k + G]] : -1;
+            if ((int)k < G) wg_first[k] = uts[u];
+        }
+        pl->grid = G;
+    } else {
+        const int G = std::max(1, std::min(pl->n_tiles, max_wg));
+        wg_first.assign(G, -1);
+        for (int t = 0; t < pl->n_tiles; t++) tiles[t].next = (t + G < pl->n_tiles) ? t + G : -1;
+        for (int g = 0; g < G && g < pl->n_tiles; g++) wg_first[g] = g;
+        pl->grid = G;
+    }
     try {
         HIP_TRY(hipSetDevice(e->device));
         pl->tiles.upload(tiles);
-        pl->d_sample_off.upload(pl->sample_off);
-        pl->d_row_off.upload(pl->row_off);
-        pl->utt_tile_start.upload(uts);
+        pl->wg_first.upload(wg_first);
         if (d.kind == ctu::FeaKind::TrapDct) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
@@ -895,19 +1135,22 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.rows = d_rows;
         kp.logmel = e->logmel.p;
         kp.tiles = pl->tiles.p;
-        kp.sample_off = pl->d_sample_off.p;
-        kp.row_off = pl->d_row_off.p;
-        kp.n_tiles = pl->n_tiles;
+        kp.wg_first = pl->wg_first.p;
         kp.lanec = e->lanec.p;
         kp.ftab = e->ftab.p;
         kp.itab = e->itab.p;
+        kp.tab_floats = e->tab_floats;
+        kp.ck_off = e->ck_off;
+        kp.cf_off = e->cf_off;
+        kp.NS = e->NS;
+        kp.CW = e->CW;
+        kp.ncoef_out = e->ncoef_out;
         kp.wshift = d.wshift;
         kp.B = d.B;
         kp.nfea = d.nfea;
         kp.D = d.D;
         kp.ncep = d.o.fea_ncepcoefs;
         kp.lporder = d.o.fea_lporder;
-        kp.dct_off = e->dct_off;
         kp.lift_off = e->lift_off;
         kp.preem = d.o.preem;
         kp.inv_window = 1.0f / (float)d.window;
@@ -918,19 +1161,37 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.nr_exten = d.o.nr_mode == "exten";
         kp.nr_p = (float)d.o.nr_p;
         kp.nr_a = (float)d.o.nr_a;
-        kp.by_utt = kp.nr_exten;
-        kp.utt_tile_start = pl->utt_tile_start.p;
-        kp.n_utt = pl->n_utt;
-        const int n_outer = kp.by_utt ? pl->n_utt : pl->n_tiles;
-        const int grid = std::max(1, std::min(n_outer, e->n_cu * 2));
+        kp.dbg = getenv("CTU_DEBUG_MODE") ? atoi(getenv("CTU_DEBUG_MODE")) : 0;
+        const int grid = pl->grid;
+#if CTU_STAMP
+        if (e->stamps.n < (size_t)grid * NWAVE * 16) e->stamps.alloc((size_t)grid * NWAVE * 16);
+        HIP_TRY(hipMemsetAsync(e->stamps.p, 0, e->stamps.n * 8, s));
+        kp.stamps = e->stamps.p;
+#endif
         HIP_TRY(hipEventRecord(e->ev0, s));
         switch (e->nz) {
-            case 13: launch_nz<13>(e->feat, dim3(grid), s, kp); break;
-            default: launch_nz<16>(e->feat, dim3(grid), s, kp); break;
+            case 13: launch_nz<13>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            default: launch_nz<16>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
         HIP_TRY(hipGetLastError());
+#if CTU_STAMP
+        if (const char *sf = getenv("CTU_STAMP_FILE")) {
+            HIP_TRY(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h(e->stamps.n);
+            HIP_TRY(hipMemcpy(h.data(), e->stamps.p, h.size() * 8, hipMemcpyDeviceToHost));
+            double sum[16] = {0};
+            for (size_t w = 0; w < (size_t)grid * NWAVE; w++)
+                for (int i = 0; i < 16; i++) sum[i] += (double)h[w * 16 + i];
+            if (FILE *f = fopen(sf, "w")) {
+                double tot = 0;
+                for (int i = 0; i < 16; i++) tot += sum[i];
+                for (int i = 0; i < 16; i++) fprintf(f, "seg %2d  mean cycles per wave %12.0f  share %.3f\n", i, sum[i] / (grid * NWAVE), sum[i] / tot);
+                fclose(f);
+            }
+        }
+#endif
         if (d.kind == ctu::FeaKind::TrapDct) {
             hipLaunchKernelGGL(trapdct_kernel, dim3(pl->n_trap_chunks), dim3(256), 0, s, e->logmel.p, d_rows, e->trapG.p,
                                pl->utt_info.p, pl->n_utt, d.B, d.o.fea_trapdct_traplen, d.o.fea_trapdct_ndct, d.D,

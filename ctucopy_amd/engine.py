@@ -40,10 +40,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB):
-        raise CtuError(CTU_ERR_DEVICE, f"{_build.LIB} is missing: run __graft_entry__.build() (hipcc, gfx950) first; "
+    path = os.environ.get("CTU_ENGINE_LIB", _build.LIB)  # override only for A/B experiments on kernel builds
+    if not os.path.exists(path):
+        raise CtuError(CTU_ERR_DEVICE, f"{path} is missing: run __graft_entry__.build() (hipcc, gfx950) first; "
                                        "there is no CPU fallback")
-    L = ctypes.CDLL(_build.LIB)
+    L = ctypes.CDLL(path)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     argv_t = ctypes.POINTER(ctypes.c_char_p)
     L.ctu_engine_create.argtypes = [ctypes.c_int, argv_t, ctypes.c_int, ctypes.POINTER(vp)]
