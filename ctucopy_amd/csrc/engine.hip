@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -36,7 +37,7 @@ namespace {
 constexpr int TILE = 64;       // frames per tile (= lanes of the per-frame phase)
 constexpr int WG = 512;        // threads per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
-constexpr int PSTRIDE = 257;   // floats per P-tile row (odd: lane-per-frame column reads are conflict-free)
+constexpr int PSTRIDE = 260;   // floats per P-tile row: 257 bins padded so rows stay 16-byte aligned (b128 reads in phase 2)
 constexpr int LDS_2WG = 80 * 1024;  // two workgroups per CU fit when a workgroup's LDS stays at or under this
 constexpr int MAX_LP = 16;     // Levinson order limit of the in-register recursion
 constexpr int MAXC = 24;       // most coefficients accumulated per frame in phase 2 (cepstra incl. c0, or LP lags)
@@ -213,8 +214,11 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
 #else
 #define STAMP(i) do { } while (0)
 #endif
+#ifndef CTU_B64A
+#define CTU_B64A 0      // experiment: one-pass float2 transpose in the first pass (raises register pressure: spills)
+#endif
 #ifndef CTU_LDSDMA
-#define CTU_LDSDMA 1    // second pass's PCM arrives by LDS-DMA during the first pass
+#define CTU_LDSDMA 0    // experiment: second pass's PCM by LDS-DMA during the first pass (no gain, costs LDS cycles)
 #endif
 template <int NZ, int FEAT>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
@@ -233,6 +237,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     cf32 *ftab = as_const(p.ftab);
     for (int i = tid; i < p.tab_floats; i += WG) ltab[i] = p.ftab[i];
     for (int i = tid; i < 16 * LANEC; i += WG) ltw[(i / LANEC) * LTW_STRIDE + (i % LANEC)] = p.lanec[i];
+    // row padding (bins 257..259) is read by phase 2 under zero weights: start it finite; only finite values
+    // (transpose scratch) are ever written there afterwards
+    for (int i = tid; i < TILE * (PSTRIDE - 257); i += WG) Pt[(i / (PSTRIDE - 257)) * PSTRIDE + 257 + i % (PSTRIDE - 257)] = 0.f;
     __syncthreads();
     const float4 *lc = reinterpret_cast<const float4 *>(ltw + l16 * LTW_STRIDE);  // this lane's constant record
     const float4 *ltw4 = lc + (LC_TW >> 2);                                       // [0,8) stage twiddles, [8,12) untangle
@@ -270,8 +277,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         constexpr bool DMA = CTU_LDSDMA && (NZ <= 15);  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
         if (p.dbg != 2 && nv > 0) {
             const int npass = nv > 4 ? 2 : 1;
-#pragma unroll 1
-            for (int it = 0; it < npass; it++) {
+            // the pass body is instantiated twice (it = 0, 1) so that the choice of transpose is made at compile time
+            auto pass = [&](auto IT) {
+                constexpr int it = decltype(IT)::value;
                 const int f = wave * 8 + it * 4 + fg;  // frame slot in tile
                 const bool file_start = (l16 == 0) && (rec.t0 + (f < nvalid ? f : nvalid - 1) == 0);
                 float *scratch = Pt + (wave * 8 + (DMA ? 4 * it : 4)) * PSTRIDE;
@@ -353,28 +361,42 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 STAMP(3);  // DFT16 #1 + twiddles
-                // ---- transpose [k1][n2] -> lane k1 holds all n2, through LDS, re then im
-                //      element (k1,n2) of frame slot fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1)
+                // ---- transpose [k1][n2] -> lane k1 holds all n2, through LDS.
+                //      element (k1,n2) of frame slot fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1): conflict-free
+                //      both ways.  Pass A has all 8 rows of the wave free: one pass of float2 (b64).  Pass B has only
+                //      rows 4-7 (rows 0-3 already hold pass A's spectra): re then im (b32).
                 const int sw = fg * 256;
                 const int par = fg & 1;
                 __builtin_amdgcn_wave_barrier();
+                if (CTU_B64A && !DMA && it == 0) {
+                    float2 *sc2 = reinterpret_cast<float2 *>(Pt + wave * 8 * PSTRIDE);
 #pragma unroll
-                for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].x;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float re[16];
+                    for (int k1 = 0; k1 < 16; k1++) sc2[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int n2 = 0; n2 < 16; n2++) re[n2] = scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                    for (int n2 = 0; n2 < 16; n2++) v[n2] = sc2[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
 #pragma unroll
-                for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].y;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                    for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].x;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    float re[16];
 #pragma unroll
-                for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)]);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                    for (int n2 = 0; n2 < 16; n2++) re[n2] = scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].y;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
 
                 STAMP(4);  // LDS transpose
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
@@ -412,7 +434,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     if (p.remove_dc) prow[0] = 1e-10f;
                 }
                 STAMP(6);  // untangle + P writes
-            }
+            };
+            pass(std::integral_constant<int, 0>{});
+            if (npass == 2) pass(std::integral_constant<int, 1>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -469,39 +493,38 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 // {first bin of the cell's chunk run, band index or -1}: the only per-lane indirection of the slot
                 const int kstart = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2]);
                 const int bidx = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2 + 1]);
-                const float *pr = prow2 + kstart;
+                const float4 *pq = reinterpret_cast<const float4 *>(prow2 + kstart);  // kstart is a multiple of 4
                 const float4 *wq = reinterpret_cast<const float4 *>(ltab) + cb * 8 + g;
                 float acc = 0.f, acc1 = 0.f;
                 const int nch = ce - cb;
                 int ch = 0;
                 for (; ch + 4 <= nch; ch += 4) {  // 4 chunks per group: 12 LDS reads in flight, then 16 FMAs
-                    float4 w4[4];
-                    float pv[16];
+                    float4 w4[4], p4[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) w4[u] = wq[(ch + u) * 8];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) pv[i] = pr[4 * ch + i];
+                    for (int u = 0; u < 4; u++) p4[u] = pq[ch + u];
 #pragma unroll
                     for (int u = 0; u < 4; u += 2) {
-                        acc += w4[u].x * pv[4 * u + 0];
-                        acc1 += w4[u + 1].x * pv[4 * u + 4];
-                        acc += w4[u].y * pv[4 * u + 1];
-                        acc1 += w4[u + 1].y * pv[4 * u + 5];
-                        acc += w4[u].z * pv[4 * u + 2];
-                        acc1 += w4[u + 1].z * pv[4 * u + 6];
-                        acc += w4[u].w * pv[4 * u + 3];
-                        acc1 += w4[u + 1].w * pv[4 * u + 7];
+                        acc += w4[u].x * p4[u].x;
+                        acc1 += w4[u + 1].x * p4[u + 1].x;
+                        acc += w4[u].y * p4[u].y;
+                        acc1 += w4[u + 1].y * p4[u + 1].y;
+                        acc += w4[u].z * p4[u].z;
+                        acc1 += w4[u + 1].z * p4[u + 1].z;
+                        acc += w4[u].w * p4[u].w;
+                        acc1 += w4[u + 1].w * p4[u + 1].w;
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // DS reads
                     __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU
                 }
                 for (; ch < nch; ch++) {
                     const float4 w4 = wq[ch * 8];
-                    const float p0 = pr[4 * ch + 0], p1 = pr[4 * ch + 1], p2 = pr[4 * ch + 2], p3 = pr[4 * ch + 3];
-                    acc += w4.x * p0;
-                    acc1 += w4.y * p1;
-                    acc += w4.z * p2;
-                    acc1 += w4.w * p3;
+                    const float4 p4 = pq[ch];
+                    acc += w4.x * p4.x;
+                    acc1 += w4.y * p4.y;
+                    acc += w4.z * p4.z;
+                    acc1 += w4.w * p4.w;
                 }
                 acc += acc1;
                 float y = acc;
@@ -796,17 +819,24 @@ void build_tables(ctu_engine *e) {
             }
         e->ncoef_out = nout;
     }
+    auto chunks_of = [&](int b) {  // chunks of 4 bins from the aligned start of the band to its last bin
+        const int k0 = d.fb_first[b] & ~3;
+        return (d.fb_last[b] - k0) / 4 + 1;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return chunks_of(x) > chunks_of(y); });
     for (int sl = 0; sl < NS; sl++) {
         int nch = 0;
-        for (int g = 0; g < 8 && sl * 8 + g < B; g++) nch = std::max(nch, (width(order[sl * 8 + g]) + 3) / 4);
-        if (4 * nch > K) throw std::runtime_error("filter band wider than the spectrum");
+        for (int g = 0; g < 8 && sl * 8 + g < B; g++) nch = std::max(nch, chunks_of(order[sl * 8 + g]));
+        if (4 * nch > PSTRIDE) throw std::runtime_error("filter band wider than the spectrum");
         slot_chunk[sl] = (int)cw.size() / 32;
         std::vector<int> kstart(8, 0);
         for (int g = 0; g < 8; g++) {
             cell[(sl * 8 + g) * 2 + 1] = -1;
             if (sl * 8 + g >= B) continue;
             const int b = order[sl * 8 + g];
-            kstart[g] = std::min(d.fb_first[b], K - 4 * nch);  // the run of nch chunks must end inside the row
+            // aligned start; the run of nch chunks must end inside the row's PSTRIDE floats (bins >= K get weight 0
+            // but are read, so the kernel keeps them finite: it zeroes the row padding once per workgroup)
+            kstart[g] = std::min(d.fb_first[b] & ~3, PSTRIDE - 4 * nch);
             cell[(sl * 8 + g) * 2] = kstart[g];
             cell[(sl * 8 + g) * 2 + 1] = b;
             for (int i = 0; i < ncoef; i++) {
