@@ -1,0 +1,381 @@
+// ctucopy -- command-line front end of the MI355X feature engine.
+//
+// Keeps the reference's command line (src/io/opts.cc:644-846), `-S` list format
+// (`fin fout [spk] [vadfile]`, src/io/batch.cc:349-356), input decoders (raw / a-law / mu-law / WAVE,
+// src/io/in.cc:434-619, src/io/amulaw.h:20-53) and feature writers (HTK src/io/out.cc:115-213, KALDI ark+scp
+// :648-781, ICSI pfile src/io/pfile.cc:435-592), so that it is a drop-in for batch feature extraction.
+// The per-frame chain itself runs on the GPU(s) behind include/ctu_engine.h; this file only moves bytes.
+//
+// Host loop (the counterpart of BATCH::process, src/io/batch.cc:326-421): files are decoded into a packed PCM
+// arena in bounded batches, utterances of a batch are sharded over the GPUs by frame count (no collective:
+// every utterance is independent), results are written in list order.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ctu_engine.h"
+#include "opts.h"
+
+namespace {
+
+struct Fatal : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct Item {
+    std::string fin, fout, spk, fvad;
+};
+
+// ---------------------------------------------------------------- decoders
+// G.711 expansion exactly as the reference computes it (src/io/amulaw.h:20-53): chord/step -> magnitude,
+// then "2x amplification" in 16-bit wrap-around arithmetic.
+int16_t g711_to_linear(uint8_t code, bool alaw) {
+    const int a = (int)(int8_t)code;  // the reference works on a (signed) char
+    const int sgn = (~(a >> 7)) & 1;
+    int mag;
+    if (!alaw) {
+        const int chord = (~(a >> 4)) & 7, step = (~a) & 0xf;
+        mag = (((2 * step) + 33) << chord) - 33;
+    } else {
+        int chord = ((a ^ 0x55) >> 4) & 7;
+        const int step = (a ^ 0x55) & 0xf;
+        mag = (step << 1) + 1;
+        if (chord > 0) mag += 32;
+        else chord = 1;
+        mag <<= chord;
+    }
+    int out = ((1 - 2 * sgn) * mag) & 0xffff;
+    out = (out << 2) & 0xffff;
+    if (out & 0x8000) out -= 65536;
+    return (int16_t)out;
+}
+
+std::vector<uint8_t> read_all(const std::string &path, const char *err) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw Fatal(err);
+    std::vector<uint8_t> buf;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    std::fclose(f);
+    return buf;
+}
+
+uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+std::vector<int16_t> decode(const ctu::Opts &o, const std::string &path) {
+    std::vector<int16_t> pcm;
+    if (o.format_in == "raw") {
+        const std::vector<uint8_t> b = read_all(path, "IN: Cannot open data file!");
+        pcm.resize(b.size() / 2);
+        for (size_t i = 0; i < pcm.size(); i++)
+            pcm[i] = (int16_t)(o.swap_in ? (b[2 * i] << 8 | b[2 * i + 1]) : (b[2 * i + 1] << 8 | b[2 * i]));
+    } else if (o.format_in == "alaw" || o.format_in == "mulaw") {
+        const std::vector<uint8_t> b = read_all(path, "IN: Cannot open data file!");
+        pcm.resize(b.size());
+        const bool alaw = o.format_in == "alaw";
+        for (size_t i = 0; i < b.size(); i++) pcm[i] = g711_to_linear(b[i], alaw);
+    } else if (o.format_in == "wave") {  // canonical 44-byte header only, like src/io/in.cc:550-597
+        const std::vector<uint8_t> b = read_all(path, "IN: Cannot open file!");
+        if (b.size() < 44 || std::memcmp(b.data(), "RIFF", 4)) throw Fatal("IN: No RIFF header in file!");
+        if (std::memcmp(b.data() + 8, "WAVE", 4)) throw Fatal("IN: Not a WAVE file!");
+        if (rd16(&b[20]) != 1) throw Fatal("IN: Not a PCM WAVE file!");
+        if ((long)rd32(&b[24]) != o.fs) throw Fatal("IN: WAVE file reports different sampling rate than specified!");
+        if (rd16(&b[22]) != 1) throw Fatal("IN: Input WAVE file is not mono!");
+        if (rd16(&b[34]) != 16) throw Fatal("IN: Not 16 bits per sample!");
+        size_t n = rd32(&b[40]) / 2;
+        n = std::min(n, (b.size() - 44) / 2);
+        pcm.resize(n);
+        for (size_t i = 0; i < n; i++) pcm[i] = (int16_t)rd16(&b[44 + 2 * i]);
+    } else {
+        throw Fatal("IN: Unknown input file format!");
+    }
+    return pcm;
+}
+
+// ---------------------------------------------------------------- writers
+void put32(std::vector<uint8_t> &v, uint32_t x, bool big) {
+    for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (big ? 24 - 8 * i : 8 * i)));
+}
+void put16(std::vector<uint8_t> &v, uint16_t x, bool big) {
+    for (int i = 0; i < 2; i++) v.push_back((uint8_t)(x >> (big ? 8 - 8 * i : 8 * i)));
+}
+void putf(std::vector<uint8_t> &v, float f, bool big) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    put32(v, x, big);
+}
+
+void write_file(const std::string &path, const std::vector<uint8_t> &bytes, const char *err) {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw Fatal(err);
+    if (!bytes.empty() && std::fwrite(bytes.data(), 1, bytes.size(), f) != bytes.size()) {
+        std::fclose(f);
+        throw Fatal("OUT: Error in stream writing!");
+    }
+    std::fclose(f);
+}
+
+// HTK: nSamples, sampPeriod (100 ns), sampSize (bytes), parmKind, then float32 rows (src/io/out.cc:115-213)
+void write_htk(const std::string &path, const float *rows, int64_t n, const ctu_dims &d) {
+    std::vector<uint8_t> b;
+    b.reserve(12 + (size_t)n * d.row_floats * 4);
+    const bool big = d.swap_out;
+    put32(b, (uint32_t)n, big);
+    put32(b, d.htk_period, big);
+    put16(b, (uint16_t)(4 * d.row_floats), big);
+    put16(b, (uint16_t)d.htk_kind, big);
+    for (int64_t i = 0; i < n * d.row_floats; i++) putf(b, rows[i], big);
+    write_file(path, b, "OUT: Cannot create output file!");
+}
+
+// KALDI binary matrix archive + index (src/io/out.cc:648-781)
+struct ArkWriter {
+    FILE *ark = nullptr, *scp = nullptr;
+    std::string arkname;
+    explicit ArkWriter(const std::string &name) : arkname(name) {
+        ark = std::fopen(name.c_str(), "wb");
+        if (!ark) throw Fatal("OUT: Cannot create output ark file!");
+        // "x.ark" -> "x.scp": text up to the first ".ark" component, as rename_path_ark_to_scp does
+        std::string scpname, rest = name;
+        bool found = false;
+        std::stringstream ss(name);
+        std::string tok;
+        while (std::getline(ss, tok, '.')) {
+            if (tok.empty()) continue;
+            if (tok == "ark") {
+                found = true;
+                break;
+            }
+            scpname += tok + ".";
+        }
+        (void)found;
+        scpname += "scp";
+        scp = std::fopen(scpname.c_str(), "wt");
+        if (!scp) throw Fatal("Cannot open output scp file for writing!");
+    }
+    void add(const std::string &key, const float *rows, int64_t n, int cols) {
+        std::fprintf(ark, "%s %cBFM %c", key.c_str(), 0, 4);
+        const long long idx = (long long)ftello(ark) - 6;  // offset of the \0 that starts the binary marker
+        const int32_t r = (int32_t)n, c = cols;
+        std::fwrite(&r, 4, 1, ark);
+        std::fputc(4, ark);
+        std::fwrite(&c, 4, 1, ark);
+        std::fprintf(scp, "%s %s:%lld\n", key.c_str(), arkname.c_str(), idx);
+        if (n) std::fwrite(rows, 4, (size_t)n * cols, ark);
+    }
+    ~ArkWriter() {
+        if (ark) std::fclose(ark);
+        if (scp) std::fclose(scp);
+    }
+};
+
+// ICSI pfile: 32768-byte ASCII header, big-endian rows [sent, frame, features], sentence index table
+// (src/io/pfile.cc:435-468,470-505,573-592).  The reference opens it with the internal vector width, not the
+// written row width (src/io/out.cc:252); that is reproduced: nfea_pf floats per row, zero padded / truncated.
+struct PfileWriter {
+    std::string name;
+    int nfea;
+    std::vector<uint8_t> data;
+    std::vector<uint32_t> sent_start{0};
+    uint32_t nframes = 0;
+    PfileWriter(const std::string &n, int nf) : name(n), nfea(nf) {}
+    void add(const float *rows, int64_t n, int cols) {
+        const uint32_t sid = (uint32_t)sent_start.size() - 1;
+        for (int64_t t = 0; t < n; t++) {
+            put32(data, sid, true);
+            put32(data, (uint32_t)t, true);
+            for (int i = 0; i < nfea; i++) putf(data, i < cols ? rows[t * cols + i] : 0.f, true);
+        }
+        nframes += (uint32_t)n;
+        sent_start.push_back(nframes);
+    }
+    void close() {
+        const unsigned long long hsize = 32768, dsize = (unsigned long long)(nfea + 2) * nframes;
+        std::string h;
+        char line[256];
+        auto addf = [&](const char *fmt, auto... a) {
+            std::snprintf(line, sizeof line, fmt, a...);
+            h += line;
+        };
+        addf("-pfile_header version %u size %llu\n", 0u, hsize);
+        addf("-num_sentences %u\n", (unsigned)sent_start.size() - 1);
+        addf("-num_frames %u\n", nframes);
+        addf("-first_feature_column %u\n", 2u);
+        addf("-num_features %u\n", (unsigned)nfea);
+        addf("-first_label_column %u\n", (unsigned)(2 + nfea));
+        addf("-num_labels %u\n", 0u);
+        h += "-format dd" + std::string(nfea, 'f') + "\n";
+        addf("-data size %llu offset %llu ndim %u nrow %u ncol %u\n", dsize, 0ull, 2u, nframes, (unsigned)(nfea + 2));
+        addf("-sent_table_data size %llu offset %llu ndim %u\n", (unsigned long long)sent_start.size(), dsize, 1u);
+        h += "-end\n";
+        std::vector<uint8_t> b(h.begin(), h.end());
+        b.resize(hsize, 0);
+        b.insert(b.end(), data.begin(), data.end());
+        for (uint32_t s : sent_start) put32(b, s, true);
+        write_file(name, b, "OUT: Cannot create output file!");
+    }
+};
+
+// ---------------------------------------------------------------- GPU side
+struct Gpu {
+    ctu_engine *eng = nullptr;
+    ~Gpu() {
+        if (eng) ctu_engine_destroy(eng);
+    }
+};
+
+void run_shard(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> &utts, std::vector<std::vector<float>> &out,
+               int row_floats, std::string &err) {
+    std::vector<int64_t> ns;
+    for (auto *u : utts) ns.push_back((int64_t)u->size());
+    ctu_plan *plan = nullptr;
+    if (ctu_plan_create(eng, ns.data(), (int)ns.size(), &plan) != CTU_OK) {
+        err = ctu_last_error(eng);
+        return;
+    }
+    const int64_t *so = ctu_plan_sample_offsets(plan), *ro = ctu_plan_row_offsets(plan);
+    std::vector<int16_t> arena((size_t)ctu_plan_total_samples(plan), 0);
+    for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena.begin() + so[i]);
+    std::vector<float> rows((size_t)ctu_plan_total_frames(plan) * row_floats);
+    if (ctu_engine_run_host(eng, plan, arena.data(), rows.data(), nullptr, nullptr) != CTU_OK) err = ctu_last_error(eng);
+    else
+        for (size_t i = 0; i < utts.size(); i++) out[i].assign(rows.begin() + ro[i] * row_floats, rows.begin() + ro[i + 1] * row_floats);
+    ctu_plan_destroy(plan);
+}
+
+int real_main(int argc, char **argv) {
+    std::vector<std::string> args;
+    int ngpu = 1;
+    for (int i = 1; i < argc; i++) {
+        if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = std::max(1, std::atoi(argv[++i]));
+        else args.emplace_back(argv[i]);
+    }
+    ctu::Opts o;
+    try {
+        o = ctu::Opts::from_args(args);
+    } catch (const ctu::OptsError &e) {
+        if (args.empty()) std::fputs(ctu::Opts().usage().c_str(), stderr);
+        throw Fatal(e.what());
+    }
+    if (o.help) {
+        std::fputs(o.usage().c_str(), stdout);
+        return 0;
+    }
+    if (o.format_out != "htk" && o.format_out != "ark" && o.format_out != "pfile")
+        throw Fatal(o.format_out.empty() ? "OUT: Unknown output file format!"
+                                         : "ENGINE: only feature outputs (htk, ark=, pfile=) are on the accelerated path");
+    // the work list
+    std::vector<Item> items;
+    if (o.pipe_in || o.pipe_out) throw Fatal("ENGINE: online (pipe) mode is not supported");
+    if (!o.in.empty()) {
+        items.push_back({o.in, o.out, "", o.vad_out});
+    } else {
+        if (o.list.empty()) throw Fatal("BATCH: Nothing to do!");
+        std::ifstream lf(o.list);
+        if (!lf) throw Fatal("BATCH: Cannot open list file!");
+        std::string line;
+        while (std::getline(lf, line)) {
+            std::istringstream ss(line);
+            Item it;
+            if (!(ss >> it.fin >> it.fout)) {
+                if (line.find_first_not_of(" \t\r") == std::string::npos) continue;
+                throw Fatal("BATCH: Bad list format!");
+            }
+            ss >> it.spk >> it.fvad;
+            if (o.do_vad() && it.fvad.empty()) throw Fatal("BATCH: Bad list format!");
+            items.push_back(it);
+        }
+    }
+    // engines, one per GPU
+    std::vector<const char *> cargs;
+    for (auto &a : args) cargs.push_back(a.c_str());
+    std::vector<Gpu> gpus(ngpu);
+    for (int g = 0; g < ngpu; g++)
+        if (ctu_engine_create((int)cargs.size(), cargs.data(), g, &gpus[g].eng) != CTU_OK) throw Fatal(ctu_create_error());
+    ctu_dims d;
+    ctu_engine_dims(gpus[0].eng, &d);
+
+    std::unique_ptr<ArkWriter> ark;
+    std::unique_ptr<PfileWriter> pf;
+    if (o.format_out == "ark") ark.reset(new ArkWriter(o.arkfilename));
+    if (o.format_out == "pfile") {
+        // internal vector width: row width without E, plus c0 when it is switched off for the row (src/io/out.cc:252)
+        int nfea_pf = d.row_floats - (o.fea_E ? 1 : 0);
+        if ((o.fea_kind == "dctc" || o.fea_kind == "lpc") && !o.fea_c0) nfea_pf += 1;
+        if (o.fea_kind == "lpa") nfea_pf += 1;
+        pf.reset(new PfileWriter(o.pfilename, nfea_pf));
+    }
+
+    const size_t batch_samples = 512u << 20;  // ~1 GiB of PCM per batch
+    size_t pos = 0;
+    while (pos < items.size()) {
+        std::vector<std::vector<int16_t>> pcm;
+        size_t total = 0, end = pos;
+        while (end < items.size() && (total < batch_samples || end == pos)) {
+            pcm.push_back(decode(o, items[end].fin));
+            if (ctu_num_frames(gpus[0].eng, (int64_t)pcm.back().size()) < 0) throw Fatal("IO: Signal shorter than one frame!");
+            total += pcm.back().size();
+            end++;
+        }
+        const size_t n = end - pos;
+        // longest-processing-time sharding over the GPUs by frame count
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pcm[a].size() > pcm[b].size(); });
+        std::vector<std::vector<size_t>> shard(ngpu);
+        std::vector<size_t> load(ngpu, 0);
+        for (size_t i : order) {
+            const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            shard[g].push_back(i);
+            load[g] += pcm[i].size();
+        }
+        std::vector<std::vector<float>> rows(n);
+        std::vector<std::string> errs(ngpu);
+        std::vector<std::thread> th;
+        for (int g = 0; g < ngpu; g++)
+            th.emplace_back([&, g] {
+                std::vector<const std::vector<int16_t> *> u;
+                std::vector<std::vector<float>> out(shard[g].size());
+                for (size_t i : shard[g]) u.push_back(&pcm[i]);
+                if (!u.empty()) run_shard(gpus[g].eng, u, out, d.row_floats, errs[g]);
+                for (size_t k = 0; k < shard[g].size(); k++) rows[shard[g][k]] = std::move(out[k]);
+            });
+        for (auto &t : th) t.join();
+        for (auto &e : errs)
+            if (!e.empty()) throw Fatal(e);
+        for (size_t i = 0; i < n; i++) {
+            const Item &it = items[pos + i];
+            const int64_t nr = (int64_t)rows[i].size() / d.row_floats;
+            if (o.verbose) std::fprintf(stderr, "processing: %s - %lld frames.\n", it.fin.c_str(), (long long)nr);
+            if (ark) ark->add(it.fout, rows[i].data(), nr, d.row_floats);
+            else if (pf) pf->add(rows[i].data(), nr, d.row_floats);
+            else write_htk(it.fout, rows[i].data(), nr, d);
+        }
+        pos = end;
+    }
+    if (pf) pf->close();
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    try {
+        return real_main(argc, argv);
+    } catch (const std::exception &e) {  // the reference prints the thrown text and returns -1 (src/main.cpp:54-60)
+        std::fprintf(stderr, "%s\n", e.what());
+        return -1;
+    }
+}

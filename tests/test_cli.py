@@ -1,0 +1,157 @@
+"""The `ctucopy` executable: command line, list format, decoders and the HTK / ark / pfile writers.
+
+Byte-level anchors come from outputs of the compiled reference recorded in SURVEY.md 8(b)/(c):
+HTK files of 30900 / 30796 bytes with header (n, 100000, 52, 8198); ark offsets 5 and 30913; a pfile of
+103940 bytes for the same two utterances.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from ctucopy_amd import build as cbuild
+from oracle.oracle import Oracle, htk_bytes
+from tests.util import C1, GOLDEN, sig
+
+CLI = cbuild.CLI
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    cbuild.build_cli()
+
+
+def run(args, cwd=None):
+    return subprocess.run([CLI] + list(args), capture_output=True, text=True, cwd=cwd)
+
+
+def test_errors_without_gpu_work(tmp_path):
+    r = run([])
+    assert r.returncode == 255 and "No command line options" in r.stderr
+    r = run(["-preset", "mfcc", "-S", "x"])
+    assert r.returncode == 255 and "sampling rate" in r.stderr
+    r = run("-fs 16000 -format_in raw -format_out htk -preset mfcc -S /nonexistent/list".split())
+    assert r.returncode == 255 and "Cannot open list file" in r.stderr
+    r = run("-fs 16000 -format_in raw -format_out raw -preset exten -S x".split())
+    assert r.returncode == 255
+    assert run(["-h"]).returncode == 0
+
+
+def _list(tmp_path, names, cols=2):
+    lines = []
+    for n in names:
+        cols_ = [os.path.join(GOLDEN, "SA000CB1." + n), str(tmp_path / (n + ".out"))]
+        if cols > 2:
+            cols_ += ["spk", str(tmp_path / (n + ".vad"))]
+        lines.append(" ".join(cols_))
+    p = tmp_path / "list.scp"
+    p.write_text("\n".join(lines) + "\n")
+    return str(p)
+
+
+def _close(a, b):
+    return (np.abs(a - b) / np.maximum(np.abs(b), 1.0)).max() <= TOL
+
+
+@pytest.mark.gpu
+def test_htk_output_matches_reference_anchors(tmp_path):
+    lst = _list(tmp_path, ["CS0", "CS3"])
+    r = run(C1 + ["-S", lst, "-v"])
+    assert r.returncode == 0, r.stderr
+    assert "594 frames" in r.stderr and "592 frames" in r.stderr
+    orc = Oracle(C1)
+    for name, size, frames in (("CS0", 30900, 594), ("CS3", 30796, 592)):
+        img = (tmp_path / (name + ".out")).read_bytes()
+        assert len(img) == size
+        assert struct.unpack("<IIHH", img[:12]) == (frames, 100000, 52, 8198)
+        got = np.frombuffer(img[12:], dtype="<f4").reshape(frames, 13)
+        ref = orc.process(sig(name))
+        assert _close(got, ref)
+        assert img[:12] == htk_bytes(ref, 100000, 8198)[:12]
+
+
+@pytest.mark.gpu
+def test_big_endian_and_single_file_mode(tmp_path):
+    out = tmp_path / "be.htk"
+    r = run(C1[:8] + ["-endian_out", "big"] + C1[8:] + ["-endian_out", "big", "-i", os.path.join(GOLDEN, "SA000CB1.CS3"),
+                                                       "-o", str(out)])
+    assert r.returncode == 0, r.stderr
+    img = out.read_bytes()
+    assert struct.unpack(">IIHH", img[:12]) == (592, 100000, 52, 8198)
+    got = np.frombuffer(img[12:], dtype=">f4").reshape(592, 13)
+    assert _close(got.astype(np.float32), Oracle(C1).process(sig("CS3")))
+
+
+@pytest.mark.gpu
+def test_ark_scp_and_pfile(tmp_path):
+    lst = tmp_path / "l.scp"
+    lst.write_text(f"{GOLDEN}/SA000CB1.CS0 uttA\n{GOLDEN}/SA000CB1.CS3 uttB\n")
+    args = [a for a in C1 if a not in ("-format_out", "htk")]
+    ark = tmp_path / "t.ark"
+    r = run(args + ["-format_out", f"ark={ark}", "-S", str(lst)])
+    assert r.returncode == 0, r.stderr
+    scp = (tmp_path / "t.scp").read_text().split("\n")
+    assert scp[0] == f"uttA {ark}:5" and scp[1] == f"uttB {ark}:30913"
+    b = ark.read_bytes()
+    assert b[:11] == b"uttA \0BFM \4" and struct.unpack("<i", b[11:15])[0] == 594 and b[15] == 4
+    assert struct.unpack("<i", b[16:20])[0] == 13
+    pfile = tmp_path / "t.pfile"
+    r = run(args + ["-format_out", f"pfile={pfile}", "-S", str(lst)])
+    assert r.returncode == 0, r.stderr
+    pb = pfile.read_bytes()
+    assert len(pb) == 103940
+    hdr = pb[:32768].split(b"\0")[0].decode()
+    assert "-num_sentences 2" in hdr and "-num_frames 1186" in hdr and "-num_features 13" in hdr
+    row0 = struct.unpack(">II13f", pb[32768:32768 + 60])
+    assert row0[:2] == (0, 0)
+    assert _close(np.array(row0[2:], dtype=np.float32), Oracle(C1).process(sig("CS0"))[0])
+    assert struct.unpack(">3I", pb[-12:]) == (0, 594, 1186)
+
+
+@pytest.mark.gpu
+def test_wave_and_alaw_inputs(tmp_path):
+    x = sig("CS3")[:32000]
+    wav = tmp_path / "a.wav"
+    hdr = b"RIFF" + struct.pack("<I", 36 + 2 * x.size) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) \
+        + b"data" + struct.pack("<I", 2 * x.size)
+    wav.write_bytes(hdr + x.astype("<i2").tobytes())
+    args = [a for a in C1]
+    args[args.index("raw")] = "wave"
+    out = tmp_path / "w.htk"
+    r = run(args + ["-i", str(wav), "-o", str(out)])
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(out.read_bytes()[12:], dtype="<f4").reshape(-1, 13)
+    assert _close(got, Oracle(C1).process(x))
+    # a-law: decode table restated from the reference formula (src/io/amulaw.h:20-53)
+    codes = np.arange(256, dtype=np.uint8)
+    a = codes.astype(np.int8).astype(np.int32)
+    sgn = (~(a >> 7)) & 1
+    chord = ((a ^ 0x55) >> 4) & 7
+    step = (a ^ 0x55) & 0xF
+    mag = (step << 1) + 1
+    mag = np.where(chord > 0, mag + 32, mag)
+    chord = np.where(chord > 0, chord, 1)
+    mag = mag << chord
+    outv = ((1 - 2 * sgn) * mag) & 0xFFFF
+    outv = (outv << 2) & 0xFFFF
+    table = np.where(outv & 0x8000, outv - 65536, outv).astype(np.int16)
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, size=24000, dtype=np.uint8)
+    (tmp_path / "x.al").write_bytes(raw.tobytes())
+    args2 = [a for a in C1]
+    args2[args2.index("raw")] = "alaw"
+    out2 = tmp_path / "al.htk"
+    r = run(args2 + ["-i", str(tmp_path / "x.al"), "-o", str(out2)])
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(out2.read_bytes()[12:], dtype="<f4").reshape(-1, 13)
+    assert _close(got, Oracle(C1).process(table[raw]))
+
+
+@pytest.mark.gpu
+def test_short_file_aborts_like_the_reference(tmp_path):
+    (tmp_path / "s.raw").write_bytes(np.zeros(100, dtype="<i2").tobytes())
+    r = run(C1 + ["-i", str(tmp_path / "s.raw"), "-o", str(tmp_path / "s.htk")])
+    assert r.returncode == 255 and "Signal shorter than one frame" in r.stderr
