@@ -29,16 +29,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3
 
 
-def utterance_lengths(n_utt, seed):
-    """3-15 s at 16 kHz, deterministic (splitmix64 on the utterance index)."""
-    i = np.arange(n_utt, dtype=np.uint64) + np.uint64(seed) * np.uint64(1000003)
-    z = (i + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    z = z ^ (z >> np.uint64(31))
-    return (48000 + (z % np.uint64(240000 - 48000 + 1))).astype(np.int64)
-
-
 def synth_arena(total_samples, seed, device):
     """Speech-like stream generated on the GPU: 4 harmonics of an f0 gliding 90-250 Hz, 4 Hz AM,
     white noise sigma~300 LSB from an integer hash of the sample index (never digitally silent)."""
@@ -100,13 +90,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=10000, help="utterances per GPU")
-    ap.add_argument("--cpu-utts", type=int, default=1536, help="utterances in the CPU baseline sample")
+    ap.add_argument("--cpu-utts", type=int, default=4096, help="utterances in the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from ctucopy_amd import Engine
+    from ctucopy_amd import Engine, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,7 +110,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     eng = Engine(CFG, device=local)
-    lens = utterance_lengths(args.utts, seed=20260101 + rank)
+    lens = shard.rank_shard(rank, args.utts)
     plan = eng.plan(lens)
     pcm = synth_arena(plan.total_samples, seed=rank, device=dev)
     rows = torch.empty((plan.total_frames, eng.dims.row_floats), dtype=torch.float32, device=dev)
@@ -146,19 +136,19 @@ def main():
     for _ in range(min(args.steps, 10)):
         eng.run_device(plan, pcm, rows, stream=stream)
         kernel_ms.append(eng.last_kernel_ms())
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    frames = torch.tensor([float(plan.total_frames)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(frames, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
-    total_frames = float(frames.item())
+    dt, total_frames = shard.reduce_timing(dt, plan.total_frames, device=dev)
 
     if rank == 0:
         d = eng.dims
         bytes_per_frame = 2 * d.wshift + 4 * d.row_floats
         k_ms = float(np.median(kernel_ms))
         achieved = plan.total_frames * bytes_per_frame / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 correction, plus
+        # WRITE_SIZE), scaled per frame; PMC counters cannot be collected inside this process
+        traffic_gb = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            traffic_gb = json.load(open(tf))["hbm_bytes_per_frame"] * plan.total_frames  # bytes per launch
         result = {
             "metric": "frames/sec (16 kHz, 25 ms/10 ms, MFCC-13)",
             "value": total_frames * args.steps / dt,
@@ -177,7 +167,7 @@ def main():
                        "frames_per_gpu": plan.total_frames, "pcm_bytes_per_gpu": plan.total_samples * 2,
                        "parallelism": f"utterance shard x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_gb,
                          "kernel": "frontend_kernel<13, DCTC>", "kernel_ms": k_ms,
                          "bytes_per_frame": bytes_per_frame},
         }

@@ -1,0 +1,42 @@
+"""Utterance sharding across ranks and the cross-rank timing reduction used by bench.py.
+
+Utterances are independent on the hot path, so N ranks = N independent shards and NO collective touches the data;
+torch.distributed (RCCL on GPUs, gloo in the CPU tests) only carries the timing barrier, max(time), sum(frames).
+"""
+import numpy as np
+
+
+def utterance_lengths(n_utt, seed, lo=48000, hi=240000):
+    """Deterministic per-shard utterance lengths in samples (3-15 s at 16 kHz): splitmix64 of the index."""
+    i = np.arange(n_utt, dtype=np.uint64) + np.uint64(seed) * np.uint64(1000003)
+    with np.errstate(over="ignore"):
+        z = i + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (lo + (z % np.uint64(hi - lo + 1))).astype(np.int64)
+
+
+def rank_shard(rank, utts_per_rank, base_seed=20260101):
+    """Weak scaling: every rank owns its own `utts_per_rank` utterances (seeded by rank)."""
+    return utterance_lengths(utts_per_rank, seed=base_seed + rank)
+
+
+def split_list(n_items, world, rank):
+    """Strong-scaling split of a fixed list (the CLI's case): contiguous, sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def reduce_timing(dt_seconds, frames, device=None):
+    """(max over ranks of dt, sum over ranks of frames); identity when torch.distributed is not initialised."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(dt_seconds), float(frames)
+    t = torch.tensor([float(dt_seconds)], dtype=torch.float64, device=device)
+    f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(f.item())
