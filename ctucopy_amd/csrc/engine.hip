@@ -69,6 +69,7 @@ struct KParams {
     // [NS][8] at ck_off | per-cell coefficient rows [NS][8][CW] at cf_off
     int tab_floats, ck_off, cf_off, NS, CW;
     int ncoef_out;              // DCTC: coefficients written per row (table rows are in output order)
+    int e_mode, e_slot, K, window;  // -fea_E: 0 none, 1 spectrum (nr->E), 2 log R[0], 3 band energy, 4 raw frame energy
     int wshift, B, nfea, D, ncep, lporder;
     int lift_off;
     float preem, inv_window;
@@ -488,6 +489,20 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             float c[MAXC];
 #pragma unroll
             for (int i = 0; i < MAXC; i++) c[i] = 0.f;
+            float esum = 0.f;
+            if (p.e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
+                const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : wave * 8) * p.wshift;
+                for (int i = 1 + g; i < p.window; i += 8) {
+                    const float x = (float)xr[i];
+                    esum += x * x;
+                }
+            }
+            if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
+                for (int k = g; k < p.K; k += 8) {
+                    const float x = prow2[k];
+                    esum += ((k == 0 || k == p.K - 1) ? 0.5f : 1.0f) * x * x;
+                }
+            }
             for (int sl = 0; sl < p.NS; sl++) {
                 const int cb = slot_chunk[sl], ce = slot_chunk[sl + 1];
                 // {first bin of the cell's chunk run, band index or -1}: the only per-lane indirection of the slot
@@ -530,6 +545,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 float y = acc;
                 if (p.fb_inld) y = __powf(y, 0.33f);  // src/fea/fb.cc:81-83
                 if (FEAT == FEAT_LOGSPEC || FEAT == FEAT_DCTC || FEAT == FEAT_LOGMEL_SCRATCH) y = __logf(y);
+                if (p.e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
+                    esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5f : 1.0f) * acc * acc;
                 if (FEAT == FEAT_SPEC || FEAT == FEAT_LOGSPEC || FEAT == FEAT_LOGMEL_SCRATCH) {
                     float *dst = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.logmel : p.rows;
                     const int out_w = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.B : p.D;
@@ -543,6 +560,12 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             STAMP(8);  // filter bank + per-band accumulation
+            if (p.e_mode && FEAT != FEAT_LOGMEL_SCRATCH) {
+                float e = 0.f;
+                if (p.e_mode == 1 || p.e_mode == 3) e = __logf(2.0f * lanes8_allreduce_add(esum));
+                else if (p.e_mode == 4) e = __logf(lanes8_allreduce_add(esum));
+                if (p.e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
+            }
             if (FEAT == FEAT_DCTC || FEAT == FEAT_LPC || FEAT == FEAT_LPA) {
                 if (p.CW == 16) cells_reduce<16>(c);
                 else cells_reduce<MAXC>(c);
@@ -566,6 +589,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const int P_ = p.lporder;
                     double a[MAX_LP + 1], cc[MAX_LP + 1];
                     const double r0 = c[0];
+                    if (p.e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = (float)log(r0);  // E = ln R[0] (src/fea/fea_impl.cc:177)
                     double rc = -(double)c[1] / r0;
                     double err = r0 * (1 - rc * rc);
                     a[0] = 1;
@@ -748,7 +772,7 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.rasta) return "-nr_rasta";
     if (o.fea_delta || o.fea_trap) return "delta / stacked features (next row N1)";
     if (o.stat_cmvn || o.apply_cmvn || o.fea_Z_exp > 0 || o.fea_Z_block > 0) return "CMVN / CMS (next row N2)";
-    if (o.fea_E) return "-fea_E on";
+    if (o.fea_E && d.kind == ctu::FeaKind::TrapDct) return "-fea_E with trapdct (the energy lags the features by 50 frames in the reference)";
     if (o.do_vad()) return "VAD module";
     if (d.wfft != 512) return "FFT size other than 512";
     if (d.wshift % 8) return "frame shift that is not a multiple of 8 samples (16-byte aligned frame starts)";
@@ -1175,6 +1199,16 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.NS = e->NS;
         kp.CW = e->CW;
         kp.ncoef_out = e->ncoef_out;
+        kp.K = d.K;
+        kp.window = d.window;
+        kp.e_slot = d.e_slot;
+        kp.e_mode = 0;
+        if (d.o.fea_E) {  // energy routing of src/io/batch.cc:98-119
+            if (d.o.fea_rawenergy) kp.e_mode = 4;
+            else if (d.kind == ctu::FeaKind::Dctc) kp.e_mode = 1;
+            else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) kp.e_mode = 2;
+            else kp.e_mode = 3;
+        }
         kp.wshift = d.wshift;
         kp.B = d.B;
         kp.nfea = d.nfea;

@@ -99,5 +99,14 @@ def test_exten_16k(Engine):
     _check(Engine, C2 + ["-nr_mode", "exten"], [synth_utt(53, 20000)])
 
 
+@pytest.mark.parametrize("cfg", [C2 + ["-fea_E", "on"], C2 + ["-fea_E", "on", "-fea_c0", "off"],
+                                 C2 + ["-fea_E", "on", "-fea_rawenergy", "on"], C3 + ["-fea_E", "on"],
+                                 C2 + ["-fea_kind", "logspec", "-fea_E", "on"], C2 + ["-fea_kind", "spec", "-fea_E", "on"],
+                                 C2 + ["-nr_mode", "exten", "-nr_a", "2", "-fea_E", "on"]])
+def test_energy_column(Engine, cfg):
+    # energy routing of src/io/batch.cc:98-119: nr->E for dctc, ln R[0] for lpc, band energy for spec kinds, raw energy
+    _check(Engine, cfg, [synth_utt(71, 20000), sig("CS0")[:20000]])
+
+
 def test_c5_trapdct(Engine):
     _check(Engine, C5, [sig("CS3"), synth_utt(61, 30000)])
