@@ -221,7 +221,10 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
 #ifndef CTU_LDSDMA
 #define CTU_LDSDMA 0    // experiment: second pass's PCM by LDS-DMA during the first pass (no gain, costs LDS cycles)
 #endif
-template <int NZ, int FEAT>
+// MODE 0: 512-point real FFT, one frame per 16-lane group, NZ = rows of 32 samples, two passes of 4 frames.
+// MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
+//         (no twiddles in the untangle), NZ = rows of 16 samples, one pass of 8 frames.
+template <int NZ, int FEAT, int MODE>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
@@ -275,9 +278,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // Pass A (frame slots 0-3 of the wave) loads its PCM from global memory and meanwhile has the PCM of
         // pass B (slots 4-7) copied by LDS-DMA into the wave's rows 4-7, which nobody needs before pass B
         // writes its spectra there.  The transpose scratch is rows 0-3 in pass A and rows 4-7 in pass B.
-        constexpr bool DMA = CTU_LDSDMA && (NZ <= 15);  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
+        constexpr bool DMA = CTU_LDSDMA && (NZ <= 15) && MODE == 0;  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
         if (p.dbg != 2 && nv > 0) {
-            const int npass = nv > 4 ? 2 : 1;
+            const int npass = (MODE == 0 && nv > 4) ? 2 : 1;
             // the pass body is instantiated twice (it = 0, 1) so that the choice of transpose is made at compile time
             auto pass = [&](auto IT) {
                 constexpr int it = decltype(IT)::value;
@@ -286,6 +289,43 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 float *scratch = Pt + (wave * 8 + (DMA ? 4 * it : 4)) * PSTRIDE;
                 STAMP(0);  // loop overhead / previous tail
                 float2 v[16];
+                if constexpr (MODE == 1) {
+                    // frames A = slot 2*fg, B = A+1 of this wave's 8; sample n = 16 j + l16 of each goes to re / im
+                    const int fa = wave * 8 + 2 * fg, fb_ = fa + 1;
+                    const int ca = fa < nvalid ? fa : nvalid - 1, cb_ = fb_ < nvalid ? fb_ : nvalid - 1;
+                    const int16_t *xa = p.pcm + rec.sbase + (int64_t)ca * p.wshift + l16;
+                    const int16_t *xb = p.pcm + rec.sbase + (int64_t)cb_ * p.wshift + l16;
+                    const bool start_a = (l16 == 0) && (rec.t0 + ca == 0), start_b = (l16 == 0) && (rec.t0 + cb_ == 0);
+                    float dca = 0.f, dcb = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];
+                        const float w = (j & 1) ? w4.z : w4.x;  // 0 beyond the window
+                        float pa = (float)xa[16 * j - 1], pb = (float)xb[16 * j - 1];
+                        const float a0 = (float)xa[16 * j], b0 = (float)xb[16 * j];
+                        if (j == 0) {
+                            pa = start_a ? 0.f : pa;
+                            pb = start_b ? 0.f : pb;
+                        }
+                        const float ya = w * (a0 - p.preem * pa), yb = w * (b0 - p.preem * pb);
+                        v[j] = make_float2(ya, yb);
+                        dca += ya;
+                        dcb += yb;
+                    }
+#pragma unroll
+                    for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
+                    STAMP(1);
+                    if (p.remove_dc) {
+                        const float ma = row16_allreduce_add(dca) * p.inv_window, mb = row16_allreduce_add(dcb) * p.inv_window;
+#pragma unroll
+                        for (int j = 0; j < NZ; j++) {
+                            const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
+                            const float mm = (j & 1) ? mk.z : mk.x;
+                            v[j].x -= ma * mm;
+                            v[j].y -= mb * mm;
+                        }
+                    }
+                } else {
                 float dc = 0.f;
                 pcm4 q[NZ];
                 if (!DMA || it == 0) {
@@ -350,6 +390,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     }
                 }
 
+                }
                 STAMP(2);  // DC removal
                 // ---- stage 1: DFT16 over n1 (registers), lane = n2; then twiddle W256^(n2*k1)
                 dft16(v);
@@ -404,6 +445,31 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 dft16(v);
                 STAMP(5);  // DFT16 #2
 
+                if constexpr (MODE == 1) {
+                    // two real frames in one complex FFT: XA[k] = (Z[k] + conj Z[256-k])/2, XB[k] = (Z[k] - conj Z[256-k])/2i;
+                    // bins 0..128 of both; the mirror bin comes from lane (16-k1)%16 as in MODE 0
+                    float *pa = Pt + (wave * 8 + 2 * fg) * PSTRIDE, *pb = pa + PSTRIDE;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) {
+                        if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
+                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        if (l16 == 0) {
+                            br = v[(16 - k2) & 15].x;
+                            bi = v[(16 - k2) & 15].y;
+                        }
+                        const float ar = v[k2].x, ai = v[k2].y;
+                        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                        const int k = l16 + 16 * k2;
+                        pa[k] = 0.25f * (sr * sr + si * si);
+                        pb[k] = 0.25f * (dr * dr + di * di);
+                    }
+                    if (l16 == 0) {
+                        pa[128] = v[8].x * v[8].x;
+                        pb[128] = v[8].y * v[8].y;
+                        if (p.remove_dc) pa[0] = pb[0] = 1e-10f;
+                    }
+                } else {
                 // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
                 //      each together with its mirror bin 256-k held by lane (16-k1)%16 in register 15-k2
                 //      (register (16-k2)%16 for k1 = 0).
@@ -434,6 +500,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
                     if (p.remove_dc) prow[0] = 1e-10f;
                 }
+                }
                 STAMP(6);  // untangle + P writes
             };
             pass(std::integral_constant<int, 0>{});
@@ -443,8 +510,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         __builtin_amdgcn_wave_barrier();
 
         if (!p.fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
-            for (int e = lane; e < nv * 257; e += 64) {
-                const int f = e / 257, k = e - f * 257;
+            for (int e = lane; e < nv * p.K; e += 64) {
+                const int f = e / p.K, k = e - f * p.K;
                 float *q_ = Pt + (wave * 8 + f) * PSTRIDE + k;
                 *q_ = sqrtf(*q_);
             }
@@ -460,7 +527,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 navg = 0.95f;
                 yavg = 0.05f;
             }
-            if (tid < 257) {
+            if (tid < p.K) {
                 const float pp = p.nr_p, qq = 1.0f - p.nr_p;
                 for (int f = 0; f < nvalid; f++) {
                     const float X = Pt[f * PSTRIDE + tid];
@@ -731,6 +798,7 @@ struct ctu_engine {
     std::string err;
     int feat = FEAT_DCTC;
     int nz = 16;
+    int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
     DevBuf<float> lanec, ftab, trapG;
     DevBuf<int> itab;
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, NS = 0, CW = 4, ncoef_out = 0;
@@ -774,8 +842,8 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.stat_cmvn || o.apply_cmvn || o.fea_Z_exp > 0 || o.fea_Z_block > 0) return "CMVN / CMS (next row N2)";
     if (o.fea_E && d.kind == ctu::FeaKind::TrapDct) return "-fea_E with trapdct (the energy lags the features by 50 frames in the reference)";
     if (o.do_vad()) return "VAD module";
-    if (d.wfft != 512) return "FFT size other than 512";
-    if (d.wshift % 8) return "frame shift that is not a multiple of 8 samples (16-byte aligned frame starts)";
+    if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
+    if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
         if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above the in-register limit";
@@ -790,16 +858,18 @@ void build_tables(ctu_engine *e) {
     const ctu::Design &d = *e->design;
     const double pi = 3.14159265358979323846;
     // ---- per-lane constant records (see LC_* above)
+    const bool mode1 = d.wfft == 256;
+    e->mode = mode1 ? 1 : 0;
     std::vector<float> lc(16 * LANEC, 0.f);
     for (int l = 0; l < 16; l++) {
         float *r = lc.data() + l * LANEC;
         for (int j = 0; j < 16; j++)
             for (int h = 0; h < 2; h++) {
-                const int i = 32 * j + 2 * l + h;
+                // MODE 0: lane l holds samples 32j+2l, +1 of row j; MODE 1: sample 16j+l (second slot unused)
+                const int i = mode1 ? (h ? d.window : 16 * j + l) : 32 * j + 2 * l + h;
                 r[LC_WIN + 2 * j + h] = i < d.window ? (float)d.hamming[i] : 0.f;
+                r[LC_MASK + 2 * j + h] = i < d.window ? 1.f : 0.f;
             }
-        for (int j = 0; j < 16; j++)
-            for (int h = 0; h < 2; h++) r[LC_MASK + 2 * j + h] = (32 * j + 2 * l + h) < d.window ? 1.f : 0.f;
         for (int k1 = 1; k1 < 16; k1++) {
             const double a = -2 * pi * (double)(k1 * l) / 256.0;
             r[LC_TW + 2 * (k1 - 1)] = (float)std::cos(a);
@@ -918,20 +988,20 @@ void build_tables(ctu_engine *e) {
         case ctu::FeaKind::Lpa: e->feat = FEAT_LPA; break;
         case ctu::FeaKind::TrapDct: e->feat = FEAT_LOGMEL_SCRATCH; break;
     }
-    e->nz = (d.window + 31) / 32;
+    e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
 }
 
-template <int NZ>
+template <int NZ, int MODE>
 void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
 #define LAUNCH(F)                                                                                      \
     case F: {                                                                                          \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F>),       \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE>),       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));        \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL((frontend_kernel<NZ, F>), grid, dim3(WG), shm, s, kp);                      \
+        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE>), grid, dim3(WG), shm, s, kp);                      \
         break;                                                                                         \
     }
     switch (feat) {
@@ -1234,8 +1304,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #endif
         HIP_TRY(hipEventRecord(e->ev0, s));
         switch (e->nz) {
-            case 13: launch_nz<13>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
-            default: launch_nz<16>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            case 13: e->mode ? launch_nz<13, 1>(e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_nz<13, 0>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            default: e->mode ? launch_nz<16, 1>(e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_nz<16, 0>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

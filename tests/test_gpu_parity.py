@@ -108,5 +108,19 @@ def test_energy_column(Engine, cfg):
     _check(Engine, cfg, [synth_utt(71, 20000), sig("CS0")[:20000]])
 
 
+def test_c4_features_8khz(Engine):
+    # configs[3] without the VAD byte stream: 8 kHz, window 200, hop 80, 256-point FFT, exten + MFCC
+    from tests.util import C4_NOVAD
+    x3 = sig("CS3")
+    _check(Engine, C4_NOVAD, [x3, synth_utt(81, 30000, fs=8000), synth_utt(82, 7000, fs=8000)])
+    _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97".split(), [x3[:40000], synth_utt(83, 12345, fs=8000)])
+    _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset plpc".split(), [x3[:40000]])
+    _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset mfcc -w 32 -s 10 -fea_E on".split(), [x3[:30000]])
+    frames = [1, 7, 8, 9, 63, 64, 65, 130]
+    utts = [synth_utt(200 + i, 120 + 80 * f + (i % 5), fs=8000) for i, f in enumerate(frames)]
+    got = Engine(C4_NOVAD).extract(utts)
+    assert [g.shape[0] for g in got] == frames
+
+
 def test_c5_trapdct(Engine):
     _check(Engine, C5, [sig("CS3"), synth_utt(61, 30000)])
