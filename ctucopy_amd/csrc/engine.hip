@@ -60,6 +60,9 @@ struct KParams {
     const int16_t *pcm;
     float *rows;
     float *logmel;              // [total_frames][B] scratch (TRAP only)
+    float2 *xri;                // [total_frames][K] complex spectrum before NR (VAD cepdist-lpc only)
+    float *pnr;                 // [total_frames][K] spectrum after NR (VAD cepdist-lpc) or [total_frames] energy (VAD energy)
+    int vad_export;             // 0 none, 1 spectra for the Burg-cepstral criterion, 2 frame energy criterion
     const struct TileRec *tiles;
     const int *wg_first;        // [grid] first tile of each workgroup's chain (-1 = none)
     const float *lanec;         // [16][LANEC]
@@ -463,11 +466,21 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         const int k = l16 + 16 * k2;
                         pa[k] = 0.25f * (sr * sr + si * si);
                         pb[k] = 0.25f * (dr * dr + di * di);
+                        if (p.vad_export == 1) {  // XA = s/2, XB = (d)/(2i) = (di - i dr)/2
+                            const int fa = wave * 8 + 2 * fg;
+                            if (fa < nvalid) p.xri[(rbase + fa) * 129 + k] = make_float2(0.5f * sr, 0.5f * si);
+                            if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + k] = make_float2(0.5f * di, -0.5f * dr);
+                        }
                     }
                     if (l16 == 0) {
                         pa[128] = v[8].x * v[8].x;
                         pb[128] = v[8].y * v[8].y;
                         if (p.remove_dc) pa[0] = pb[0] = 1e-10f;
+                        if (p.vad_export == 1) {
+                            const int fa = wave * 8 + 2 * fg;
+                            if (fa < nvalid) p.xri[(rbase + fa) * 129 + 128] = make_float2(v[8].x, 0.f);
+                            if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + 128] = make_float2(v[8].y, 0.f);
+                        }
                     }
                 } else {
                 // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
@@ -495,10 +508,16 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const int k = l16 + 16 * k2;
                     prow[k] = pk;
                     prow[256 - k] = pm;
+                    if (p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
+                        float2 *xo = p.xri + (rbase + f) * 257;
+                        xo[k] = make_float2(0.5f * ur, 0.5f * ui);
+                        xo[256 - k] = make_float2(0.5f * vr, -0.5f * vi);
+                    }
                 }
                 if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
                     prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
                     if (p.remove_dc) prow[0] = 1e-10f;
+                    if (p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
                 }
                 }
                 STAMP(6);  // untangle + P writes
@@ -531,17 +550,46 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 const float pp = p.nr_p, qq = 1.0f - p.nr_p;
                 for (int f = 0; f < nvalid; f++) {
                     const float X = Pt[f * PSTRIDE + tid];
-                    float H;
-                    if (p.nr_a == 1.0f) H = navg / (navg + yavg);
-                    else if (p.nr_a == 2.0f) H = navg / sqrtf(navg * navg + yavg * yavg);
-                    else H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
+                    // H = Navg / (Navg^a + Yavg^a)^(1/a); the output X - H X is formed as X (1 - H) with 1 - H written
+                    // without cancellation (fp32 here, double in the reference; double was measured: no accuracy gain,
+                    // -15 % on the main path through register allocation)
+                    float H, omH;
+                    if (p.nr_a == 1.0f) {
+                        const float r = navg + yavg;
+                        H = navg / r;
+                        omH = yavg / r;
+                    } else if (p.nr_a == 2.0f) {
+                        const float r = sqrtf(navg * navg + yavg * yavg);
+                        H = navg / r;
+                        omH = (yavg * yavg) / (r * (r + navg));
+                    } else {
+                        H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
+                        omH = 1.0f - H;
+                    }
                     const float N = H * X;
                     navg = pp * navg + qq * N;
                     yavg = fabsf(X - navg);
-                    Pt[f * PSTRIDE + tid] = X - N;
+                    Pt[f * PSTRIDE + tid] = X * omH;
                 }
             }
             __syncthreads();
+        }
+        if (p.vad_export && nv > 0) {  // the VAD looks at in->_Xsabs after NR (src/io/batch.cc:230-240, src/vad/vad.cc:96-107,227-230)
+            if (p.vad_export == 1) {
+                for (int e = lane; e < nv * p.K; e += 64) {
+                    const int f = e / p.K, k = e - f * p.K;
+                    p.pnr[(rbase + wave * 8 + f) * p.K + k] = Pt[(wave * 8 + f) * PSTRIDE + k];
+                }
+            } else {
+                const int f8e = lane >> 3, ge = lane & 7;
+                float es = 0.f;
+                for (int k = ge; k < p.K; k += 8) {
+                    const float x = Pt[(wave * 8 + f8e) * PSTRIDE + k];
+                    es += x * x;
+                }
+                es = lanes8_allreduce_add(es);
+                if (ge == 0 && f8e < nv) p.pnr[rbase + wave * 8 + f8e] = es;
+            }
         }
         STAMP(7);  // hand-over to phase 2 (incl. NR)
 
@@ -720,6 +768,230 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// VAD module (src/vad/vad.cc, src/vad/vad.h, src/vdet/Burg.h).  Decisions are discontinuous, so this side path
+// computes in double.  Kernel A is frame-parallel (HC2R of the post-NR spectrum with the original phase, Burg
+// lattice, a -> c); kernel B is one thread per utterance and replays the sequential part: cepstral distance to
+// the adaptive background, threshold recurrences, background update, majority ("median") filter.
+// ------------------------------------------------------------------------------------------------
+struct VadParams {
+    int K, wfft, window, ncoef;  // ncoef = vad_lpc_coefs (cepdist lpc) or feature vector length (cepdist fea)
+    int cri;                     // 0 energy, 1 cepdist-lpc, 2 cepdist-fea
+    int thr;                     // 0 absolute, 1 perc, 2 adapt, 3 dyn
+    int energy_db, cep_init, filter_order;
+    double cep_p, abs_thr, perc_thr, adapt_q, adapt_za, dyn_perc, dyn_min, qmaxinc, qmaxdec, qmindec, qmininc;
+    int perc_init, adapt_init, dyn_init;
+    int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
+};
+
+// One workgroup (256 threads) per frame.
+__global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
+                                                       double *__restrict__ ci_out, VadParams vp, int64_t total_frames) {
+    __shared__ double hr[257], hi[257];      // halfcomplex input: Xa cos(phi), Xa sin(phi)   (vad.cc:227-230)
+    __shared__ double ef[512], eb[512], red[2][256];
+    __shared__ double tw_c[512], tw_s[512];
+    __shared__ double a[32], aa[32], cc[32];
+    const int64_t fr = blockIdx.x;
+    if (fr >= total_frames) return;
+    const int tid = threadIdx.x, K = vp.K, n = vp.wfft, W = vp.window, nc = vp.ncoef;
+    for (int i = tid; i < n; i += 256) {
+        double sv, cv;
+        sincos(2.0 * 3.14159265358979323846 * (double)i / (double)n, &sv, &cv);
+        tw_c[i] = cv;
+        tw_s[i] = sv;
+    }
+    for (int k = tid; k < K; k += 256) {
+        const float2 x = xri[fr * K + k];
+        const double xa = pnr[fr * K + k];
+        double c = 1.0, s_ = 0.0;  // Xph[0] = 0 (src/io/in.cc:398)
+        if (k > 0) {
+            const double mag = sqrt((double)x.x * x.x + (double)x.y * x.y);
+            if (mag > 0) {
+                c = x.x / mag;
+                s_ = x.y / mag;
+            } else {  // c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193); the last bin is 0 or pi by the sign of re (:399)
+                c = (k == K - 1) ? 1.0 : 0.0;
+                s_ = (k == K - 1) ? 0.0 : -1.0;
+            }
+            if (k == K - 1) s_ = 0.0;
+        }
+        hr[k] = xa * c;
+        hi[k] = xa * s_;
+    }
+    __syncthreads();
+    // FFTW_HC2R, unnormalised: x_j = r0 + 2 sum_{k=1}^{n/2-1} (r_k cos(2 pi jk/n) - i_k sin(2 pi jk/n)) + (-1)^j r_{n/2}
+    for (int j = tid; j < W; j += 256) {
+        double acc = hr[0] + ((j & 1) ? -hr[K - 1] : hr[K - 1]);
+        for (int k = 1; k < K - 1; k++) {
+            const int m = (j * k) & (n - 1);
+            acc += 2.0 * (hr[k] * tw_c[m] - hi[k] * tw_s[m]);
+        }
+        ef[j] = eb[j] = acc;
+    }
+    __syncthreads();
+    // Burg lattice (src/vdet/Burg.h:49-95)
+    double part = 0.0;
+    for (int j = tid; j < W; j += 256) part += ef[j] * ef[j];
+    red[0][tid] = part;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[0][tid] += red[0][tid + st];
+        __syncthreads();
+    }
+    double alpha = red[0][0] / (double)W;
+    __syncthreads();
+    if (tid == 0) a[0] = 1.0;
+    for (int ik = 1; ik < nc; ik++) {
+        double num = 0.0, den = 0.0;
+        for (int i = ik + tid; i < W; i += 256) {
+            den += ef[i] * ef[i] + eb[i - 1] * eb[i - 1];
+            num += ef[i] * eb[i - 1];
+        }
+        red[0][tid] = num;
+        red[1][tid] = den;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                red[0][tid] += red[0][tid + st];
+                red[1][tid] += red[1][tid + st];
+            }
+            __syncthreads();
+        }
+        const double rc = -(2.0 * red[0][0]) / red[1][0];
+        alpha *= 1.0 - rc * rc;
+        // filter the error signals: both updates use the old values
+        double nef[2], neb[2];
+        int cnt = 0;
+        for (int i = 1 + tid; i < W; i += 256) {
+            nef[cnt] = ef[i] + rc * eb[i - 1];
+            neb[cnt] = eb[i - 1] + rc * ef[i];
+            cnt++;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = 1 + tid; i < W; i += 256) {
+            ef[i] = nef[cnt];
+            eb[i] = neb[cnt];
+            cnt++;
+        }
+        if (tid == 0) {
+            a[ik] = rc;
+            for (int i = 1; i < ik; i++) a[i] = aa[i] + rc * aa[ik - i];
+            for (int i = 1; i <= ik; i++) aa[i] = a[i];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {  // Burg2Cepstrum (src/vdet/Burg.h:141-152)
+        for (int m = 1; m < nc; m++) {
+            double sum = 0.0;
+            for (int k = 1; k < m; k++) sum += (m - k) * cc[m - k] * a[k];
+            cc[m] = -a[m] - sum / m;
+        }
+        cc[0] = log(alpha);
+        for (int m = 0; m < nc; m++) ci_out[fr * nc + m] = cc[m];
+    }
+}
+
+// One thread per utterance (src/vad/vad.cc:220-294 distance + background, :329-625 thresholds, vad.h:126-175 filter).
+__global__ void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
+                                  const float *__restrict__ rows, const int64_t *__restrict__ row_off,
+                                  int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_utt) return;
+    const int64_t r0 = row_off[u];
+    const int T = (int)(row_off[u + 1] - r0);
+    const int nc = vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
+    double c0[32], ci[32];
+    int hist[33];
+    for (int i = 0; i < order; i++) hist[i] = 0;
+    int hidx = 0, nout = 0;
+    double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
+    int adapt_vad = 0;
+    for (int t = 0; t < T; t++) {
+        double cri;
+        if (vp.cri == 0) {
+            double en = cri_energy[r0 + t];
+            if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
+            cri = en;
+        } else {
+            if (vp.cri == 1) {
+                for (int i = 0; i < nc; i++) ci[i] = ci_all[(r0 + t) * nc + i];
+            } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131)
+                const float *row = rows + (r0 + t) * vp.D;
+                ci[0] = vp.c0_slot >= 0 ? (double)row[vp.c0_slot] : 0.0;
+                for (int i = 1; i < nc; i++) ci[i] = row[i - 1];
+            }
+            if (t == 0) {
+                for (int i = 0; i < nc; i++) c0[i] = ci[i];
+                cri = 0.0;
+            } else {
+                if (t == 1)
+                    for (int i = 0; i < nc; i++) c0[i] = (c0[i] + ci[i]) / 2.0;
+                double sum = 0.0;
+                for (int i = 1; i < nc; i++) sum += (ci[i] - c0[i]) * (ci[i] - c0[i]);
+                cri = 4.3429 * sqrt(2 * sum);
+            }
+        }
+        int vad0;
+        if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
+        else if (vp.thr == 1) {
+            if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
+            else {
+                crimin = cri < crimin ? cri : crimin;
+                crimax = cri > crimax ? cri : crimax;
+            }
+            vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
+        } else if (vp.thr == 2) {
+            if (t == 0) {
+                crimean = cri;
+                crimean2 = cri * cri;
+                crivar = 0.0;
+                adapt_vad = 0;
+            } else {
+                const double thr = crimean + vp.adapt_za * sqrt(crivar);
+                if (cri < thr || t <= vp.adapt_init) {
+                    crimean = vp.adapt_q * crimean + (1.0 - vp.adapt_q) * cri;
+                    crimean2 = vp.adapt_q * crimean2 + (1.0 - vp.adapt_q) * cri * cri;
+                    crivar = crimean2 - crimean * crimean;
+                    adapt_vad = 0;
+                } else adapt_vad = 1;
+            }
+            vad0 = adapt_vad;
+        } else {
+            const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
+            if (t < init) {
+                dmax = dmin = cri;
+                vad0 = 0;
+            } else if (t == init) {
+                dmax = (cri > dmax ? cri : dmax) + vp.dyn_min / 10.0;
+                dmin = (cri < dmin ? cri : dmin) - vp.dyn_min / 10.0;
+                vad0 = 0;
+            } else {
+                dmax = dmax < cri ? vp.qmaxinc * dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * dmax + (1.0 - vp.qmaxdec) * cri;
+                dmin = dmin > cri ? vp.qmindec * dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * dmin + (1.0 - vp.qmininc) * cri;
+                const double dyn = dmax - dmin;
+                vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
+            }
+        }
+        if (vp.cri != 0 && !(vad0 && t > vp.cep_init))
+            for (int i = 0; i < nc; i++) c0[i] = vp.cep_p * c0[i] + (1.0 - vp.cep_p) * ci[i];
+        hist[hidx] = vad0;
+        hidx = (hidx + 1) % order;
+        if (t >= h) {
+            int sum = 0;
+            for (int i = 0; i < order; i++) sum += hist[i];
+            vad_out[r0 + nout++] = ((double)sum / (double)order >= 0.5) ? '1' : '0';
+        }
+    }
+    for (int k = 0; k < h && nout < T; k++) {  // flush: zeros pushed (src/vad/vad.h:156-175)
+        hist[hidx] = 0;
+        hidx = (hidx + 1) % order;
+        int sum = 0;
+        for (int i = 0; i < order; i++) sum += hist[i];
+        vad_out[r0 + nout++] = ((double)sum / (double)order >= 0.5) ? '1' : '0';
+    }
+}
+
 // TRAP-DCT (src/fea/fea_trap.cc:53-127): out[t][b*ndct+k] = sum_j G[k][j] * logmel[clamp(t-half+j)][b]
 // with mean removal, Hamming and REDFT10 folded into G on the host (rows of G sum to zero, so the centre
 // frame's value is subtracted first to keep the fp32 accumulation small).  One thread per (t, b).
@@ -807,6 +1079,8 @@ struct ctu_engine {
     bool timed = false;
     DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
     DevBuf<unsigned long long> stamps;
+    bool do_vad = false;
+    VadParams vp;
 };
 
 struct ctu_plan {
@@ -818,6 +1092,10 @@ struct ctu_plan {
     int grid = 0;               // workgroups of the front-end launch (tile chains are built for it)
     DevBuf<TileRec> tiles;
     DevBuf<int> wg_first;
+    DevBuf<float2> xri;         // VAD scratch
+    DevBuf<float> pnr;
+    DevBuf<double> vad_ci;
+    DevBuf<int64_t> d_row_off;
     // TRAP
     DevBuf<int4> utt_info;
     DevBuf<int> trap_chunks;
@@ -841,7 +1119,17 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.fea_delta || o.fea_trap) return "delta / stacked features (next row N1)";
     if (o.stat_cmvn || o.apply_cmvn || o.fea_Z_exp > 0 || o.fea_Z_block > 0) return "CMVN / CMS (next row N2)";
     if (o.fea_E && d.kind == ctu::FeaKind::TrapDct) return "-fea_E with trapdct (the energy lags the features by 50 frames in the reference)";
-    if (o.do_vad()) return "VAD module";
+    if (o.do_vad()) {
+        if (d.kind == ctu::FeaKind::TrapDct) return "VAD together with trapdct";
+        if (o.vad_cri_mode != "energy" && o.vad_cri_mode != "cepdist") return "";  // rejected with the reference's text at create
+        if (o.vad_cri_mode == "cepdist") {
+            if (o.vad_cepdist_mode == "in") return "-vad_cepdist_mode in (HTK feature input)";
+            if (o.vad_cepdist_mode == "fea" && d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "-vad_cepdist_mode fea on non-cepstral features";
+            const int nc = o.vad_cepdist_mode == "lpc" ? o.vad_lpc_coefs : d.nfea;
+            if (nc > 32 || nc < 2) return "more than 32 (or fewer than 2) VAD cepstral coefficients";
+        }
+        if (o.vad_filter_order > 31) return "VAD filter order above 31";
+    }
     if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
     if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
     if (d.window < 32) return "window shorter than 32 samples";
@@ -1091,6 +1379,21 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
         g_create_error = ex.what();
         return CTU_ERR_OPTS;
     }
+    {
+        const ctu::Opts &o = e->design->o;
+        if (o.do_vad()) {  // constructor checks of src/vad/vad.cc:639-660, :149-195 and src/vad/vad.h:96-99
+            const char *bad = nullptr;
+            if (o.vad_cri_mode != "energy" && o.vad_cri_mode != "cepdist") bad = "VAD: unknown vad_cri_mode!";
+            else if (o.vad_thr_mode != "absolute" && o.vad_thr_mode != "perc" && o.vad_thr_mode != "adapt" && o.vad_thr_mode != "dyn") bad = "VAD: unknown vad_thr_mode!";
+            else if (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode != "lpc" && o.vad_cepdist_mode != "fea" && o.vad_cepdist_mode != "in") bad = "VADcri_cepdist: unknown vad_cepdist_mode!";
+            else if (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" && !o.phase_needed) bad = "VADcri_cepdist: cannot perform iFFT!";
+            else if (o.vad_filter_order < 1 || o.vad_filter_order % 2 == 0) bad = "medianFilter: filter order must be positive, odd number!";
+            if (bad) {
+                g_create_error = bad;
+                return CTU_ERR_OPTS;
+            }
+        }
+    }
     const std::string why = unsupported_reason(*e->design);
     if (!why.empty()) {
         g_create_error = "ENGINE: configuration not on the accelerated path: " + why;
@@ -1106,6 +1409,23 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
         e->device = device;
         e->n_cu = prop.multiProcessorCount;
         build_tables(e.get());
+        {
+            const ctu::Opts &o = e->design->o;
+            const ctu::Design &d = *e->design;
+            e->do_vad = o.do_vad();
+            VadParams &vp = e->vp;
+            std::memset(&vp, 0, sizeof vp);
+            vp.K = d.K; vp.wfft = d.wfft; vp.window = d.window;
+            vp.cri = o.vad_cri_mode == "energy" ? 0 : (o.vad_cepdist_mode == "lpc" ? 1 : 2);
+            vp.ncoef = vp.cri == 1 ? o.vad_lpc_coefs : d.nfea;
+            vp.thr = o.vad_thr_mode == "absolute" ? 0 : o.vad_thr_mode == "perc" ? 1 : o.vad_thr_mode == "adapt" ? 2 : 3;
+            vp.energy_db = o.vad_energy_db; vp.cep_init = o.vad_cepdist_init; vp.filter_order = o.vad_filter_order;
+            vp.cep_p = o.vad_cepdist_p; vp.abs_thr = o.vad_absolute_thr; vp.perc_thr = o.vad_perc_thr;
+            vp.adapt_q = o.vad_adapt_q; vp.adapt_za = o.vad_adapt_za; vp.dyn_perc = o.vad_dyn_perc; vp.dyn_min = o.vad_dyn_min;
+            vp.qmaxinc = o.vad_dyn_qmaxinc; vp.qmaxdec = o.vad_dyn_qmaxdec; vp.qmindec = o.vad_dyn_qmindec; vp.qmininc = o.vad_dyn_qmininc;
+            vp.perc_init = o.vad_perc_init; vp.adapt_init = o.vad_adapt_init; vp.dyn_init = o.vad_dyn_init;
+            vp.D = d.D; vp.ncep = o.fea_ncepcoefs; vp.c0_slot = d.row_slot.empty() ? -1 : d.row_slot[0];
+        }
         HIP_TRY(hipEventCreate(&e->ev0));
         HIP_TRY(hipEventCreate(&e->ev1));
     } catch (const std::exception &ex) {
@@ -1221,6 +1541,14 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
         HIP_TRY(hipSetDevice(e->device));
         pl->tiles.upload(tiles);
         pl->wg_first.upload(wg_first);
+        if (e->do_vad) {
+            pl->d_row_off.upload(pl->row_off);
+            if (e->vp.cri == 1) {
+                pl->xri.alloc((size_t)ro * d.K);
+                pl->pnr.alloc((size_t)ro * d.K);
+                pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
+            } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
+        }
         if (d.kind == ctu::FeaKind::TrapDct) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
@@ -1243,9 +1571,8 @@ int64_t ctu_plan_total_frames(const ctu_plan *p) { return p->total_frames; }
 
 int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, float *d_rows, uint8_t *d_vad, void *stream) {
     if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
-    (void)d_vad;
     if (pl->n_tiles == 0) return CTU_OK;
-    if (!d_pcm || !d_rows) {
+    if (!d_pcm || !d_rows || (e->do_vad && !d_vad)) {
         set_error(e, "ENGINE: null device buffer");
         return CTU_ERR_INPUT;
     }
@@ -1258,6 +1585,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.pcm = d_pcm;
         kp.rows = d_rows;
         kp.logmel = e->logmel.p;
+        kp.xri = pl->xri.p;
+        kp.pnr = pl->pnr.p;
+        kp.vad_export = !e->do_vad ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0));
         kp.tiles = pl->tiles.p;
         kp.wg_first = pl->wg_first.p;
         kp.lanec = e->lanec.p;
@@ -1326,6 +1656,14 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             }
         }
 #endif
+        if (e->do_vad) {
+            if (e->vp.cri == 1)
+                hipLaunchKernelGGL(vad_burg_kernel, dim3((unsigned)pl->total_frames), dim3(256), 0, s, pl->xri.p, pl->pnr.p,
+                                   pl->vad_ci.p, e->vp, pl->total_frames);
+            hipLaunchKernelGGL(vad_decide_kernel, dim3((pl->n_utt + 63) / 64), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
+                               pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
+            HIP_TRY(hipGetLastError());
+        }
         if (d.kind == ctu::FeaKind::TrapDct) {
             hipLaunchKernelGGL(trapdct_kernel, dim3(pl->n_trap_chunks), dim3(256), 0, s, e->logmel.p, d_rows, e->trapG.p,
                                pl->utt_info.p, pl->n_utt, d.B, d.o.fea_trapdct_traplen, d.o.fea_trapdct_ndct, d.D,
@@ -1350,15 +1688,33 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl, const int16_t *h_pcm,
         HIP_TRY(hipSetDevice(e->device));
         DevBuf<int16_t> pcm;
         DevBuf<float> rows;
+        DevBuf<uint8_t> vad;
         pcm.alloc((size_t)pl->total_samples);
         rows.alloc((size_t)pl->total_frames * d.D);
-        HIP_TRY(hipMemset(pcm.p, 0, (size_t)pl->total_samples * 2));
+        if (e->do_vad) vad.alloc((size_t)pl->total_frames);
         HIP_TRY(hipMemcpy(pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
-        int rc = ctu_engine_run(e, pl, pcm.p, rows.p, nullptr, nullptr);
+        int rc = ctu_engine_run(e, pl, pcm.p, rows.p, vad.p, nullptr);
         if (rc != CTU_OK) return rc;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h_rows, rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost));
-        (void)h_vad;
+        if (e->do_vad) {
+            std::vector<uint8_t> v((size_t)pl->total_frames);
+            HIP_TRY(hipMemcpy(v.data(), vad.p, v.size(), hipMemcpyDeviceToHost));
+            if (h_vad) std::memcpy(h_vad, v.data(), v.size());
+            if (d.o.vad_apply_mode == "drop") {
+                // rows of non-speech frames are dropped (src/io/batch.cc:237-238): compact each utterance in place
+                for (int i = 0; i < pl->n_utt; i++) {
+                    const int64_t r0 = pl->row_off[i], T = pl->frames[i];
+                    int64_t keep = 0;
+                    for (int64_t t = 0; t < T; t++)
+                        if (v[r0 + t] == '1') {
+                            if (keep != t) std::memmove(h_rows + (r0 + keep) * d.D, h_rows + (r0 + t) * d.D, (size_t)d.D * 4);
+                            keep++;
+                        }
+                    if (rows_per_utt) rows_per_utt[i] = keep;
+                }
+            }
+        }
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;

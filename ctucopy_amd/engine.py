@@ -181,23 +181,29 @@ class Engine:
                                                   vad.data_ptr() if vad is not None else None, s.cuda_stream))
         return rows
 
-    def run_host(self, plan, arena):
-        """numpy int16 arena in, numpy float32 rows out (H2D + kernels + D2H inside the library)."""
+    def run_host(self, plan, arena, want_vad=False):
+        """numpy int16 arena in, numpy float32 rows out (H2D + kernels + D2H inside the library).
+
+        With want_vad: (rows, vad bytes '0'/'1' per frame, rows actually kept per utterance)."""
         arena = np.ascontiguousarray(arena, dtype=np.int16)
         assert arena.size >= plan.total_samples
         rows = np.empty((plan.total_frames, self.dims.row_floats), dtype=np.float32)
         per = np.zeros(plan.n_utt, dtype=np.int64)
-        self._check(load_library().ctu_engine_run_host(self._h, plan._h, arena.ctypes.data, rows.ctypes.data, None,
-                                                       per.ctypes.data))
+        vad = np.zeros(max(plan.total_frames, 1), dtype=np.uint8)
+        self._check(load_library().ctu_engine_run_host(self._h, plan._h, arena.ctypes.data, rows.ctypes.data,
+                                                       vad.ctypes.data if self.dims.has_vad else None, per.ctypes.data))
+        if want_vad:
+            return rows, vad[:plan.total_frames], per
         return rows
 
     def last_kernel_ms(self):
         return float(load_library().ctu_engine_last_kernel_ms(self._h))
 
-    def extract(self, utterances):
-        """Convenience: list of int16 arrays -> list of [frames, D] float32 arrays."""
+    def extract(self, utterances, want_vad=False):
+        """Convenience: list of int16 arrays -> list of [rows, D] float32 arrays (and the VAD byte strings)."""
         plan = self.plan([len(u) for u in utterances])
-        rows = self.run_host(plan, plan.pack(utterances))
-        out = [rows[plan.row_off[i]:plan.row_off[i + 1]] for i in range(plan.n_utt)]
+        rows, vad, per = self.run_host(plan, plan.pack(utterances), want_vad=True)
+        out = [rows[plan.row_off[i]:plan.row_off[i] + per[i]] for i in range(plan.n_utt)]
+        vads = [vad[plan.row_off[i]:plan.row_off[i + 1]] for i in range(plan.n_utt)]
         plan.close()
-        return out
+        return (out, vads) if want_vad else out

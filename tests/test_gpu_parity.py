@@ -122,5 +122,56 @@ def test_c4_features_8khz(Engine):
     assert [g.shape[0] for g in got] == frames
 
 
+def _vad_agreement(Engine, cfg, utts, min_agree):
+    eng = Engine(cfg)
+    rows, vads = eng.extract(utts, want_vad=True)
+    orc = Oracle(cfg)
+    agree = total = 0
+    for u, r, v in zip(utts, rows, vads):
+        ref_rows, ref_vad = orc.process(u, want_vad=True)
+        assert v.size == ref_vad.size and set(np.unique(v)) <= {ord("0"), ord("1")}
+        agree += int((v == ref_vad).sum())
+        total += v.size
+        if "drop" not in cfg:
+            # Appendix-B C4 has no pre-emphasis; on the bundled 16 kHz recordings read at 8 kHz the spectrum tilts by
+            # ~80 dB and fp32 FFT noise reaches |d| ~ 1e-4 on rows whose values reach 85: 2e-4 element-wise (unit
+            # floor), 1e-5 relative to the row's largest value
+            assert r.shape == ref_rows.shape and rel_err(r, ref_rows) <= 2e-4
+            assert (np.abs(r - ref_rows).max(axis=1) <= 1e-5 * np.maximum(np.abs(ref_rows).max(axis=1), 1.0)).all()
+    assert agree / total >= min_agree, (agree, total)
+    return rows, vads
+
+
+def test_c4_burg_cepstral_vad(Engine):
+    # configs[3]: exten + Burg-cepstral VAD + MFCC at 8 kHz.  Decisions are discontinuous: agreement, not tolerance.
+    from tests.util import C4
+    rows, vads = _vad_agreement(Engine, C4, [sig("CS3"), sig("CS0"), synth_utt(91, 24000, fs=8000)], 0.995)
+    assert vads[0].size == 1186
+    assert abs(int((vads[0] == ord("1")).sum()) - 626) <= 6   # the compiled reference wrote 626 ones
+
+
+@pytest.mark.parametrize("extra,min_agree", [
+    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "perc"], 0.995),
+    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "adapt"], 0.99),
+    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "dyn", "-vad_filter_order", "5"], 0.99),
+    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "absolute", "-vad_absolute_thr", "150"], 0.995),
+    (["-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "adapt"], 0.99),
+    (["-vad", "burg", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_thr_mode", "adapt"], 0.99),
+])
+def test_vad_modes_16k(Engine, extra, min_agree):
+    _vad_agreement(Engine, C2 + extra, [sig("CS0")[:48000], synth_utt(92, 30000)], min_agree)
+
+
+def test_vad_drop_mode_row_counts(Engine):
+    cfg = C2 + ["-vad_out_mode", "vad", "-vad_apply_mode", "drop", "-vad_cri_mode", "energy", "-vad_thr_mode", "perc"]
+    utts = [sig("CS0")[:48000], synth_utt(93, 20000)]
+    rows, vads = Engine(cfg).extract(utts, want_vad=True)
+    full = Engine(C2).extract(utts)
+    for r, v, f in zip(rows, vads, full):
+        keep = v == ord("1")
+        assert r.shape[0] == int(keep.sum())
+        assert np.array_equal(r, f[keep])
+
+
 def test_c5_trapdct(Engine):
     _check(Engine, C5, [sig("CS3"), synth_utt(61, 30000)])
