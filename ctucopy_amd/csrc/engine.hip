@@ -54,7 +54,9 @@ constexpr int LC_WIN = 0, LC_MASK = 32, LC_TW = 64, LC_UT = 96, LANEC = 112;
 // ~1k cycles.  Row stride 116 floats makes the 16 lanes' ds_read_b128 conflict-free (116 mod 64 = 52).
 constexpr int LTW_STRIDE = 116, LTW_FLOATS = 16 * LTW_STRIDE;
 
-enum FeatMode { FEAT_SPEC = 0, FEAT_LOGSPEC = 1, FEAT_DCTC = 2, FEAT_LPC = 3, FEAT_LPA = 4, FEAT_LOGMEL_SCRATCH = 5 };
+// Kernel variants by feature tail.  BANDS covers spec / logspec / the log-mel scratch of TRAP (runtime flags
+// band_log, band_to_scratch); LP covers lpc and lpa (runtime flag lp_is_lpa).
+enum FeatMode { FEAT_BANDS = 0, FEAT_DCTC = 2, FEAT_LP = 3 };
 
 struct KParams {
     const int16_t *pcm;
@@ -63,6 +65,7 @@ struct KParams {
     float2 *xri;                // [total_frames][K] complex spectrum before NR (VAD cepdist-lpc only)
     float *pnr;                 // [total_frames][K] spectrum after NR (VAD cepdist-lpc) or [total_frames] energy (VAD energy)
     int vad_export;             // 0 none, 1 spectra for the Burg-cepstral criterion, 2 frame energy criterion
+    int band_log, band_to_scratch, lp_is_lpa;
     const struct TileRec *tiles;
     const int *wg_first;        // [grid] first tile of each workgroup's chain (-1 = none)
     const float *lanec;         // [16][LANEC]
@@ -227,7 +230,8 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
 // MODE 0: 512-point real FFT, one frame per 16-lane group, NZ = rows of 32 samples, two passes of 4 frames.
 // MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
 //         (no twiddles in the untangle), NZ = rows of 16 samples, one pass of 8 frames.
-template <int NZ, int FEAT, int MODE>
+// VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
+template <int NZ, int FEAT, int MODE, bool VX>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         const int k = l16 + 16 * k2;
                         pa[k] = 0.25f * (sr * sr + si * si);
                         pb[k] = 0.25f * (dr * dr + di * di);
-                        if (p.vad_export == 1) {  // XA = s/2, XB = (d)/(2i) = (di - i dr)/2
+                        if (VX && p.vad_export == 1) {  // XA = s/2, XB = (d)/(2i) = (di - i dr)/2
                             const int fa = wave * 8 + 2 * fg;
                             if (fa < nvalid) p.xri[(rbase + fa) * 129 + k] = make_float2(0.5f * sr, 0.5f * si);
                             if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + k] = make_float2(0.5f * di, -0.5f * dr);
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         pa[128] = v[8].x * v[8].x;
                         pb[128] = v[8].y * v[8].y;
                         if (p.remove_dc) pa[0] = pb[0] = 1e-10f;
-                        if (p.vad_export == 1) {
+                        if (VX && p.vad_export == 1) {
                             const int fa = wave * 8 + 2 * fg;
                             if (fa < nvalid) p.xri[(rbase + fa) * 129 + 128] = make_float2(v[8].x, 0.f);
                             if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + 128] = make_float2(v[8].y, 0.f);
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const int k = l16 + 16 * k2;
                     prow[k] = pk;
                     prow[256 - k] = pm;
-                    if (p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
+                    if (VX && p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
                         float2 *xo = p.xri + (rbase + f) * 257;
                         xo[k] = make_float2(0.5f * ur, 0.5f * ui);
                         xo[256 - k] = make_float2(0.5f * vr, -0.5f * vi);
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
                     prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
                     if (p.remove_dc) prow[0] = 1e-10f;
-                    if (p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
+                    if (VX && p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
                 }
                 }
                 STAMP(6);  // untangle + P writes
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             }
             __syncthreads();
         }
-        if (p.vad_export && nv > 0) {  // the VAD looks at in->_Xsabs after NR (src/io/batch.cc:230-240, src/vad/vad.cc:96-107,227-230)
+        if (VX && p.vad_export && nv > 0) {  // the VAD looks at in->_Xsabs after NR (src/io/batch.cc:230-240, src/vad/vad.cc:96-107,227-230)
             if (p.vad_export == 1) {
                 for (int e = lane; e < nv * p.K; e += 64) {
                     const int f = e / p.K, k = e - f * p.K;
@@ -659,15 +663,15 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 acc += acc1;
                 float y = acc;
                 if (p.fb_inld) y = __powf(y, 0.33f);  // src/fea/fb.cc:81-83
-                if (FEAT == FEAT_LOGSPEC || FEAT == FEAT_DCTC || FEAT == FEAT_LOGMEL_SCRATCH) y = __logf(y);
+                if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __logf(y);
                 if (p.e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
                     esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5f : 1.0f) * acc * acc;
-                if (FEAT == FEAT_SPEC || FEAT == FEAT_LOGSPEC || FEAT == FEAT_LOGMEL_SCRATCH) {
-                    float *dst = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.logmel : p.rows;
-                    const int out_w = (FEAT == FEAT_LOGMEL_SCRATCH) ? p.B : p.D;
+                if (FEAT == FEAT_BANDS) {
+                    float *dst = p.band_to_scratch ? p.logmel : p.rows;
+                    const int out_w = p.band_to_scratch ? p.B : p.D;
                     if (bidx >= 0 && fvalid) dst[(rbase + fslot) * out_w + bidx] = y;
                 } else {
-                    if ((FEAT == FEAT_LPC || FEAT == FEAT_LPA) && !p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
+                    if (FEAT == FEAT_LP && !p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
                     const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * p.CW);
                     if (p.CW == 16) cell_accumulate<16>(c, cf, y);
@@ -675,13 +679,13 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             STAMP(8);  // filter bank + per-band accumulation
-            if (p.e_mode && FEAT != FEAT_LOGMEL_SCRATCH) {
+            if (p.e_mode && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
                 float e = 0.f;
                 if (p.e_mode == 1 || p.e_mode == 3) e = __logf(2.0f * lanes8_allreduce_add(esum));
                 else if (p.e_mode == 4) e = __logf(lanes8_allreduce_add(esum));
                 if (p.e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
             }
-            if (FEAT == FEAT_DCTC || FEAT == FEAT_LPC || FEAT == FEAT_LPA) {
+            if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
                 if (p.CW == 16) cells_reduce<16>(c);
                 else cells_reduce<MAXC>(c);
                 float *orow = p.rows + (rbase + fslot) * p.D;
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                             err *= (1 - rc * rc);
                         }
                     }
-                    if (FEAT == FEAT_LPA) {
+                    if (p.lp_is_lpa) {
 #pragma unroll
                         for (int i = 1; i <= MAX_LP; i++)
                             if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = (float)a[i];
@@ -1269,38 +1273,41 @@ void build_tables(ctu_engine *e) {
         e->trapG.upload(g);
     }
     switch (d.kind) {
-        case ctu::FeaKind::Spec: e->feat = FEAT_SPEC; break;
-        case ctu::FeaKind::LogSpec: e->feat = FEAT_LOGSPEC; break;
+        case ctu::FeaKind::Spec:
+        case ctu::FeaKind::LogSpec:
+        case ctu::FeaKind::TrapDct: e->feat = FEAT_BANDS; break;
         case ctu::FeaKind::Dctc: e->feat = FEAT_DCTC; break;
-        case ctu::FeaKind::Lpc: e->feat = FEAT_LPC; break;
-        case ctu::FeaKind::Lpa: e->feat = FEAT_LPA; break;
-        case ctu::FeaKind::TrapDct: e->feat = FEAT_LOGMEL_SCRATCH; break;
+        case ctu::FeaKind::Lpc:
+        case ctu::FeaKind::Lpa: e->feat = FEAT_LP; break;
     }
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
 }
 
-template <int NZ, int MODE>
+template <int NZ, int MODE, bool VX>
 void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
 #define LAUNCH(F)                                                                                      \
     case F: {                                                                                          \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE>),       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));        \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE>), grid, dim3(WG), shm, s, kp);                      \
+        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX>), grid, dim3(WG), shm, s, kp);             \
         break;                                                                                         \
     }
     switch (feat) {
-        LAUNCH(FEAT_SPEC)
-        LAUNCH(FEAT_LOGSPEC)
+        LAUNCH(FEAT_BANDS)
         LAUNCH(FEAT_DCTC)
-        LAUNCH(FEAT_LPC)
-        LAUNCH(FEAT_LPA)
-        LAUNCH(FEAT_LOGMEL_SCRATCH)
+        LAUNCH(FEAT_LP)
     }
 #undef LAUNCH
+}
+
+template <int NZ, int MODE>
+void launch_vx(bool vx, int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
+    if (vx) launch_nz<NZ, MODE, true>(feat, grid, s, kp, shm);
+    else launch_nz<NZ, MODE, false>(feat, grid, s, kp, shm);
 }
 
 std::vector<std::string> to_args(int argc, const char *const *argv) {
@@ -1587,6 +1594,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.logmel = e->logmel.p;
         kp.xri = pl->xri.p;
         kp.pnr = pl->pnr.p;
+        kp.band_log = d.kind != ctu::FeaKind::Spec;
+        kp.band_to_scratch = d.kind == ctu::FeaKind::TrapDct;
+        kp.lp_is_lpa = d.kind == ctu::FeaKind::Lpa;
         kp.vad_export = !e->do_vad ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0));
         kp.tiles = pl->tiles.p;
         kp.wg_first = pl->wg_first.p;
@@ -1634,8 +1644,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #endif
         HIP_TRY(hipEventRecord(e->ev0, s));
         switch (e->nz) {
-            case 13: e->mode ? launch_nz<13, 1>(e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_nz<13, 0>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
-            default: e->mode ? launch_nz<16, 1>(e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_nz<16, 0>(e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            case 13: e->mode ? launch_vx<13, 1>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_vx<13, 0>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            default: e->mode ? launch_vx<16, 1>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_vx<16, 0>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes); break;
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

@@ -170,7 +170,7 @@ def test_vad_drop_mode_row_counts(Engine):
     for r, v, f in zip(rows, vads, full):
         keep = v == ord("1")
         assert r.shape[0] == int(keep.sum())
-        assert np.array_equal(r, f[keep])
+        assert rel_err(r, f[keep]) <= 1e-5   # two instantiations of the kernel (with / without the VAD export)
 
 
 def test_c5_trapdct(Engine):
