@@ -237,7 +237,7 @@ struct Gpu {
 };
 
 void run_shard(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> &utts, std::vector<std::vector<float>> &out,
-               int row_floats, std::string &err) {
+               std::vector<std::string> &vad_out, bool has_vad, int row_floats, std::string &err) {
     std::vector<int64_t> ns;
     for (auto *u : utts) ns.push_back((int64_t)u->size());
     ctu_plan *plan = nullptr;
@@ -249,9 +249,16 @@ void run_shard(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> 
     std::vector<int16_t> arena((size_t)ctu_plan_total_samples(plan), 0);
     for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena.begin() + so[i]);
     std::vector<float> rows((size_t)ctu_plan_total_frames(plan) * row_floats);
-    if (ctu_engine_run_host(eng, plan, arena.data(), rows.data(), nullptr, nullptr) != CTU_OK) err = ctu_last_error(eng);
+    std::vector<uint8_t> vad(has_vad ? (size_t)ctu_plan_total_frames(plan) : 0);
+    std::vector<int64_t> kept(utts.size());
+    if (ctu_engine_run_host(eng, plan, arena.data(), rows.data(), has_vad ? vad.data() : nullptr, kept.data()) != CTU_OK)
+        err = ctu_last_error(eng);
     else
-        for (size_t i = 0; i < utts.size(); i++) out[i].assign(rows.begin() + ro[i] * row_floats, rows.begin() + ro[i + 1] * row_floats);
+        for (size_t i = 0; i < utts.size(); i++) {
+            // rows_per_utt < frames only with -vad_apply_mode drop (rows compacted in place by the library)
+            out[i].assign(rows.begin() + ro[i] * row_floats, rows.begin() + (ro[i] + kept[i]) * row_floats);
+            if (has_vad) vad_out[i].assign(vad.begin() + ro[i], vad.begin() + ro[i + 1]);
+        }
     ctu_plan_destroy(plan);
 }
 
@@ -342,15 +349,20 @@ int real_main(int argc, char **argv) {
             load[g] += pcm[i].size();
         }
         std::vector<std::vector<float>> rows(n);
+        std::vector<std::string> vads(n);
         std::vector<std::string> errs(ngpu);
         std::vector<std::thread> th;
         for (int g = 0; g < ngpu; g++)
             th.emplace_back([&, g] {
                 std::vector<const std::vector<int16_t> *> u;
                 std::vector<std::vector<float>> out(shard[g].size());
+                std::vector<std::string> vout(shard[g].size());
                 for (size_t i : shard[g]) u.push_back(&pcm[i]);
-                if (!u.empty()) run_shard(gpus[g].eng, u, out, d.row_floats, errs[g]);
-                for (size_t k = 0; k < shard[g].size(); k++) rows[shard[g][k]] = std::move(out[k]);
+                if (!u.empty()) run_shard(gpus[g].eng, u, out, vout, d.has_vad != 0, d.row_floats, errs[g]);
+                for (size_t k = 0; k < shard[g].size(); k++) {
+                    rows[shard[g][k]] = std::move(out[k]);
+                    vads[shard[g][k]] = std::move(vout[k]);
+                }
             });
         for (auto &t : th) t.join();
         for (auto &e : errs)
@@ -359,6 +371,10 @@ int real_main(int argc, char **argv) {
             const Item &it = items[pos + i];
             const int64_t nr = (int64_t)rows[i].size() / d.row_floats;
             if (o.verbose) std::fprintf(stderr, "processing: %s - %lld frames.\n", it.fin.c_str(), (long long)nr);
+            if (d.has_vad && o.vad_out_mode != "none") {  // one ASCII '0'/'1' per frame (src/vad/vad.h:67-70)
+                if (it.fvad.empty()) throw Fatal("VAD::new_file(): invalid filename!");
+                write_file(it.fvad, std::vector<uint8_t>(vads[i].begin(), vads[i].end()), "FileWriter: cannot open file!");
+            }
             if (ark) ark->add(it.fout, rows[i].data(), nr, d.row_floats);
             else if (pf) pf->add(rows[i].data(), nr, d.row_floats);
             else write_htk(it.fout, rows[i].data(), nr, d);

@@ -155,3 +155,18 @@ def test_short_file_aborts_like_the_reference(tmp_path):
     (tmp_path / "s.raw").write_bytes(np.zeros(100, dtype="<i2").tobytes())
     r = run(C1 + ["-i", str(tmp_path / "s.raw"), "-o", str(tmp_path / "s.htk")])
     assert r.returncode == 255 and "Signal shorter than one frame" in r.stderr
+
+
+@pytest.mark.gpu
+def test_vad_file_and_four_column_list(tmp_path):
+    from tests.util import C4
+    lst = _list(tmp_path, ["CS3"], cols=4)
+    r = run(C4 + ["-S", lst])
+    assert r.returncode == 0, r.stderr
+    vad = (tmp_path / "CS3.vad").read_bytes()
+    assert len(vad) == 1186 and set(vad) <= {ord("0"), ord("1")}
+    assert abs(vad.count(b"1") - 626) <= 6          # the compiled reference wrote 626 ones
+    assert len((tmp_path / "CS3.out").read_bytes()) == 12 + 1186 * 52
+    # a two-column list is a format error when the VAD is on (src/io/batch.cc:356)
+    r = run(C4 + ["-S", _list(tmp_path, ["CS3"], cols=2)])
+    assert r.returncode == 255 and "Bad list format" in r.stderr
