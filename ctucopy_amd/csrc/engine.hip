@@ -663,7 +663,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 acc += acc1;
                 float y = acc;
                 if (p.fb_inld) y = __powf(y, 0.33f);  // src/fea/fb.cc:81-83
-                if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __logf(y);
+                // v_log_f32 (log2, ~1 ulp) * ln 2: band energies of int16 speech are far from the denormal range
+                if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __builtin_amdgcn_logf(y) * 0.69314718056f;
                 if (p.e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
                     esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5f : 1.0f) * acc * acc;
                 if (FEAT == FEAT_BANDS) {
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 } else {
                     if (FEAT == FEAT_LP && !p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
-                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * p.CW);
+                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (p.CW + 4));  // +4: bank spread
                     if (p.CW == 16) cell_accumulate<16>(c, cf, y);
                     else cell_accumulate<MAXC>(c, cf, y);
                 }
@@ -1146,6 +1147,184 @@ std::string unsupported_reason(const ctu::Design &d) {
     return "";
 }
 
+// Host-side image of the phase-2 LDS tables (see KParams for the layout).
+struct Phase2Tables {
+    std::vector<float> ft;   // LDS image followed by the lifter
+    std::vector<int> it;     // slot_chunk[NS+1] | row_slot[nfea]
+    std::vector<int> cells, slot_chunk;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+};
+
+void build_phase2(const ctu::Design &d, Phase2Tables &t) {
+    // ---- phase-2 tables.  Bands are dealt to (slot, group) cells: sorted by width, eight per slot, so that the
+    // eight lanes of a frame walk bands of similar width in lock step.  A band is cut into 4-bin chunks whose
+    // bin range stays inside [0,K); weights outside the band's own [first,last] are zero.
+    const int B = d.B, K = d.K;
+    std::vector<int> order(B);
+    for (int b = 0; b < B; b++) order[b] = b;
+    auto width = [&](int b) { return d.fb_last[b] - d.fb_first[b] + 1; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return width(x) > width(y); });
+    const int NS = (B + 7) / 8;
+    int ncoef = 0;
+    const std::vector<double> *coef_tab = nullptr;
+    if (d.kind == ctu::FeaKind::Dctc) { coef_tab = &d.dct; ncoef = d.nfea; }
+    else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) { coef_tab = &d.idft; ncoef = d.o.fea_lporder + 1; }
+    if (ncoef > MAXC) throw std::runtime_error("more cepstral / LP coefficients than the kernel accumulates");
+    const int CW = ncoef <= 16 ? 16 : MAXC;  // the kernel has straight-line code for these two widths
+    std::vector<int> slot_chunk(NS + 1, 0);
+    std::vector<float> cw;                  // chunk weights [NC][8][4]
+    std::vector<int> cell(NS * 8 * 2, 0);   // {first bin of the chunk run, band index or -1}
+    const int CWS = CW + 4;  // row stride: 20 or 28 floats = 5 or 7 16-byte units, distinct mod 16 over the 8 groups
+    std::vector<float> cf((size_t)NS * 8 * CWS, 0.f);
+    // DCTC: coefficient row r of a cell is the value written to output slot r (c1..cN, then c0)
+    std::vector<int> coef_of_slot;
+    if (d.kind == ctu::FeaKind::Dctc) {
+        coef_of_slot.assign(d.nfea, -1);
+        int nout = 0;
+        for (int i = 0; i < d.nfea; i++)
+            if (d.row_slot[i] >= 0) {
+                coef_of_slot[d.row_slot[i]] = i;
+                nout = std::max(nout, d.row_slot[i] + 1);
+            }
+        t.ncoef_out = nout;
+    }
+    auto chunks_of = [&](int b) {  // chunks of 4 bins from the aligned start of the band to its last bin
+        const int k0 = d.fb_first[b] & ~3;
+        return (d.fb_last[b] - k0) / 4 + 1;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return chunks_of(x) > chunks_of(y); });
+    for (int sl = 0; sl < NS; sl++) {
+        int nch = 0;
+        for (int g = 0; g < 8 && sl * 8 + g < B; g++) nch = std::max(nch, chunks_of(order[sl * 8 + g]));
+        if (4 * nch > PSTRIDE) throw std::runtime_error("filter band wider than the spectrum");
+        slot_chunk[sl] = (int)cw.size() / 32;
+        // Phase 2 reads P with one ds_read_b128 per lane; the 16-byte unit a lane touches is
+        // (frame + kstart/4 + chunk) mod 16 (rows are 65 units apart).  A b128 wave access is served in four groups of
+        // 16 lanes = {frame f: groups 0-3, f+1: groups 4-7, f+2: groups 4-7, f+3: groups 0-3}; collisions depend only
+        // on a_g = kstart_g/4.  Search the assignment of this slot's bands to groups (and up to `slack` leading
+        // zero chunks) for the fewest colliding lane pairs.
+        std::vector<int> perm(8), best_perm(8), lead(8, 0), best_lead(8, 0);
+        for (int g = 0; g < 8; g++) perm[g] = best_perm[g] = sl * 8 + g < B ? order[sl * 8 + g] : -1;
+        auto a_of = [&](int b, int ld) { return b < 0 ? -1000 : (std::min(d.fb_first[b] & ~3, PSTRIDE - 4 * nch) / 4 - ld); };
+        auto cost = [&](const std::vector<int> &pm, const std::vector<int> &ld) {
+            int c = 0, a[8];
+            for (int g = 0; g < 8; g++) a[g] = a_of(pm[g], ld[g]);
+            const int fo[4] = {0, 1, 2, 3}, lo[4] = {1, 0, 0, 1};  // frame offset, uses groups 0-3 (1) or 4-7 (0)
+            int unit[16], n = 0;
+            for (int q = 0; q < 4; q++)
+                for (int g = lo[q] ? 0 : 4; g < (lo[q] ? 4 : 8); g++) unit[n++] = a[g] < -500 ? -1 - n : ((a[g] + fo[q]) % 16 + 16) % 16;
+            for (int i = 0; i < 16; i++)
+                for (int j = i + 1; j < 16; j++) c += (unit[i] >= 0 && unit[i] == unit[j]);
+            return c;
+        };
+        {
+            int best = cost(perm, lead);
+            uint32_t rng = 12345u + sl;
+            for (int it = 0; it < 4000 && best > 0; it++) {
+                std::vector<int> pm = best_perm, ld = best_lead;
+                rng = rng * 1664525u + 1013904223u;
+                const int i = (rng >> 8) % 8, j = (rng >> 16) % 8;
+                std::swap(pm[i], pm[j]);
+                std::swap(ld[i], ld[j]);
+                rng = rng * 1664525u + 1013904223u;
+                const int g = (rng >> 8) % 8;
+                if (pm[g] >= 0) {
+                    // leading zero chunks are allowed while the run still starts at >= 0 and ends beyond the last bin
+                    const int k0 = std::min(d.fb_first[pm[g]] & ~3, PSTRIDE - 4 * nch);
+                    const int mx = std::min({3, k0 / 4, (k0 + 4 * nch - (d.fb_last[pm[g]] + 1)) / 4});
+                    ld[g] = mx > 0 ? (int)((rng >> 20) % (mx + 1)) : 0;
+                }
+                const int c = cost(pm, ld);
+                if (c <= best) {
+                    best = c;
+                    best_perm = pm;
+                    best_lead = ld;
+                }
+            }
+        }
+        std::vector<int> kstart(8, 0);
+        for (int g = 0; g < 8; g++) {
+            cell[(sl * 8 + g) * 2 + 1] = -1;
+            if (best_perm[g] < 0) continue;
+            const int b = best_perm[g];
+            // aligned start; the run of nch chunks must end inside the row's PSTRIDE floats (bins >= K get weight 0
+            // but are read, so the kernel keeps them finite: it zeroes the row padding once per workgroup)
+            kstart[g] = std::min(d.fb_first[b] & ~3, PSTRIDE - 4 * nch) - 4 * best_lead[g];
+            cell[(sl * 8 + g) * 2] = kstart[g];
+            cell[(sl * 8 + g) * 2 + 1] = b;
+            for (int i = 0; i < ncoef; i++) {
+                const int src = (d.kind == ctu::FeaKind::Dctc) ? coef_of_slot[i] : i;
+                if (src >= 0) cf[((size_t)sl * 8 + g) * CWS + i] = (float)(*coef_tab)[(size_t)src * B + b];
+            }
+        }
+        for (int ch = 0; ch < nch; ch++)
+            for (int g = 0; g < 8; g++)
+                for (int i = 0; i < 4; i++) {
+                    float w = 0.f;
+                    if (best_perm[g] >= 0) {
+                        const int b = best_perm[g], k = kstart[g] + 4 * ch + i;
+                        if (k >= d.fb_first[b] && k <= d.fb_last[b]) w = (float)d.fb[b][k];
+                    }
+                    cw.push_back(w);
+                }
+    }
+    slot_chunk[NS] = (int)cw.size() / 32;
+    std::vector<float> ft(cw);
+    t.cells = cell;
+    t.slot_chunk = slot_chunk;
+    auto push_ints = [&](const std::vector<int> &v) {
+        for (int x : v) {
+            float f;
+            std::memcpy(&f, &x, 4);
+            ft.push_back(f);
+        }
+        while (ft.size() & 3) ft.push_back(0.f);
+    };
+    t.ck_off = (int)ft.size();
+    push_ints(cell);
+    t.cf_off = (int)ft.size();
+    ft.insert(ft.end(), cf.begin(), cf.end());
+    while (ft.size() & 3) ft.push_back(0.f);
+    t.tab_floats = (int)ft.size();
+    t.NS = NS;
+    t.CW = CW;
+    t.lift_off = (int)ft.size();
+    for (double v : d.lifter) ft.push_back((float)v);
+    ft.push_back(0.f);
+    t.ft = ft;
+    std::vector<int> it(slot_chunk);
+    it.insert(it.end(), d.row_slot.begin(), d.row_slot.end());
+    t.it = it;
+}
+
+// Rebuilds every band's dense weight row from the chunk tables and returns the largest deviation from the
+// float-rounded filter bank (0 when the tables are consistent).
+double check_phase2(const ctu::Design &d, const Phase2Tables &t) {
+    double worst = 0;
+    std::vector<int> seen(d.B, 0);
+    for (int sl = 0; sl < t.NS; sl++)
+        for (int g = 0; g < 8; g++) {
+            const int kstart = t.cells[(sl * 8 + g) * 2], b = t.cells[(sl * 8 + g) * 2 + 1];
+            if (b < 0) continue;
+            seen[b]++;
+            std::vector<double> row(PSTRIDE, 0.0);
+            for (int ch = t.slot_chunk[sl]; ch < t.slot_chunk[sl + 1]; ch++)
+                for (int i = 0; i < 4; i++) {
+                    const int k = kstart + 4 * (ch - t.slot_chunk[sl]) + i;
+                    if (k < 0 || k >= PSTRIDE) return 1e30;
+                    row[k] += t.ft[(size_t)(ch * 8 + g) * 4 + i];
+                }
+            for (int k = 0; k < PSTRIDE; k++) {
+                const double want = (k < d.K && k >= d.fb_first[b] && k <= d.fb_last[b]) ? (double)(float)d.fb[b][k] : 0.0;
+                if (std::fabs(row[k] - want) > 0 && getenv("CTU_P2_DEBUG")) fprintf(stderr, "sl %d g %d band %d k %d kstart %d first %d last %d row %g want %g nch %d\n", sl, g, b, k, kstart, d.fb_first[b], d.fb_last[b], row[k], want, t.slot_chunk[sl+1]-t.slot_chunk[sl]);
+                worst = std::max(worst, std::fabs(row[k] - want));
+            }
+        }
+    for (int b = 0; b < d.B; b++)
+        if (seen[b] != 1) return 1e30;
+    return worst;
+}
+
 void build_tables(ctu_engine *e) {
     const ctu::Design &d = *e->design;
     const double pi = 3.14159265358979323846;
@@ -1174,98 +1353,18 @@ void build_tables(ctu_engine *e) {
         }
     }
     e->lanec.upload(lc);
-    // ---- phase-2 tables.  Bands are dealt to (slot, group) cells: sorted by width, eight per slot, so that the
-    // eight lanes of a frame walk bands of similar width in lock step.  A band is cut into 4-bin chunks whose
-    // bin range stays inside [0,K); weights outside the band's own [first,last] are zero.
-    const int B = d.B, K = d.K;
-    std::vector<int> order(B);
-    for (int b = 0; b < B; b++) order[b] = b;
-    auto width = [&](int b) { return d.fb_last[b] - d.fb_first[b] + 1; };
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return width(x) > width(y); });
-    const int NS = (B + 7) / 8;
-    int ncoef = 0;
-    const std::vector<double> *coef_tab = nullptr;
-    if (d.kind == ctu::FeaKind::Dctc) { coef_tab = &d.dct; ncoef = d.nfea; }
-    else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) { coef_tab = &d.idft; ncoef = d.o.fea_lporder + 1; }
-    if (ncoef > MAXC) throw std::runtime_error("more cepstral / LP coefficients than the kernel accumulates");
-    const int CW = ncoef <= 16 ? 16 : MAXC;  // the kernel has straight-line code for these two widths
-    std::vector<int> slot_chunk(NS + 1, 0);
-    std::vector<float> cw;                  // chunk weights [NC][8][4]
-    std::vector<int> cell(NS * 8 * 2, 0);   // {first bin of the chunk run, band index or -1}
-    std::vector<float> cf((size_t)NS * 8 * CW, 0.f);
-    // DCTC: coefficient row r of a cell is the value written to output slot r (c1..cN, then c0)
-    std::vector<int> coef_of_slot;
-    if (d.kind == ctu::FeaKind::Dctc) {
-        coef_of_slot.assign(d.nfea, -1);
-        int nout = 0;
-        for (int i = 0; i < d.nfea; i++)
-            if (d.row_slot[i] >= 0) {
-                coef_of_slot[d.row_slot[i]] = i;
-                nout = std::max(nout, d.row_slot[i] + 1);
-            }
-        e->ncoef_out = nout;
-    }
-    auto chunks_of = [&](int b) {  // chunks of 4 bins from the aligned start of the band to its last bin
-        const int k0 = d.fb_first[b] & ~3;
-        return (d.fb_last[b] - k0) / 4 + 1;
-    };
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return chunks_of(x) > chunks_of(y); });
-    for (int sl = 0; sl < NS; sl++) {
-        int nch = 0;
-        for (int g = 0; g < 8 && sl * 8 + g < B; g++) nch = std::max(nch, chunks_of(order[sl * 8 + g]));
-        if (4 * nch > PSTRIDE) throw std::runtime_error("filter band wider than the spectrum");
-        slot_chunk[sl] = (int)cw.size() / 32;
-        std::vector<int> kstart(8, 0);
-        for (int g = 0; g < 8; g++) {
-            cell[(sl * 8 + g) * 2 + 1] = -1;
-            if (sl * 8 + g >= B) continue;
-            const int b = order[sl * 8 + g];
-            // aligned start; the run of nch chunks must end inside the row's PSTRIDE floats (bins >= K get weight 0
-            // but are read, so the kernel keeps them finite: it zeroes the row padding once per workgroup)
-            kstart[g] = std::min(d.fb_first[b] & ~3, PSTRIDE - 4 * nch);
-            cell[(sl * 8 + g) * 2] = kstart[g];
-            cell[(sl * 8 + g) * 2 + 1] = b;
-            for (int i = 0; i < ncoef; i++) {
-                const int src = (d.kind == ctu::FeaKind::Dctc) ? coef_of_slot[i] : i;
-                if (src >= 0) cf[((size_t)sl * 8 + g) * CW + i] = (float)(*coef_tab)[(size_t)src * B + b];
-            }
-        }
-        for (int ch = 0; ch < nch; ch++)
-            for (int g = 0; g < 8; g++)
-                for (int i = 0; i < 4; i++) {
-                    float w = 0.f;
-                    if (sl * 8 + g < B) {
-                        const int b = order[sl * 8 + g], k = kstart[g] + 4 * ch + i;
-                        if (k >= d.fb_first[b] && k <= d.fb_last[b]) w = (float)d.fb[b][k];
-                    }
-                    cw.push_back(w);
-                }
-    }
-    slot_chunk[NS] = (int)cw.size() / 32;
-    std::vector<float> ft(cw);
-    auto push_ints = [&](const std::vector<int> &v) {
-        for (int x : v) {
-            float f;
-            std::memcpy(&f, &x, 4);
-            ft.push_back(f);
-        }
-        while (ft.size() & 3) ft.push_back(0.f);
-    };
-    e->ck_off = (int)ft.size();
-    push_ints(cell);
-    e->cf_off = (int)ft.size();
-    ft.insert(ft.end(), cf.begin(), cf.end());
-    while (ft.size() & 3) ft.push_back(0.f);
-    e->tab_floats = (int)ft.size();
-    e->NS = NS;
-    e->CW = CW;
-    e->lift_off = (int)ft.size();
-    for (double v : d.lifter) ft.push_back((float)v);
-    ft.push_back(0.f);
-    e->ftab.upload(ft);
-    std::vector<int> it(slot_chunk);
-    it.insert(it.end(), d.row_slot.begin(), d.row_slot.end());
-    e->itab.upload(it);
+    Phase2Tables t;
+    build_phase2(d, t);
+    if (check_phase2(d, t) != 0.0) throw std::runtime_error("internal: phase-2 chunk tables do not reproduce the filter bank");
+    e->ncoef_out = t.ncoef_out;
+    e->ck_off = t.ck_off;
+    e->cf_off = t.cf_off;
+    e->tab_floats = t.tab_floats;
+    e->NS = t.NS;
+    e->CW = t.CW;
+    e->lift_off = t.lift_off;
+    e->ftab.upload(t.ft);
+    e->itab.upload(t.it);
     e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS) * sizeof(float);
     if (e->lds_bytes > 160 * 1024) throw std::runtime_error("configuration needs more than 160 KiB of LDS");
     if (d.kind == ctu::FeaKind::TrapDct) {
@@ -1363,6 +1462,11 @@ int64_t ctu_config_table(int argc, const char *const *argv, const char *name, do
         else if (n == "idft") v = d.idft;
         else if (n == "trap") v = d.trap;
         else if (n == "lifter") v = d.lifter;
+        else if (n == "phase2_check") {
+            Phase2Tables t;
+            build_phase2(d, t);
+            v = {check_phase2(d, t), (double)t.slot_chunk.back(), (double)t.NS};
+        }
         else {
             g_create_error = "unknown table name";
             return CTU_ERR_INPUT;

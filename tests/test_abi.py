@@ -79,3 +79,14 @@ def test_unsupported_configurations_are_reported_not_approximated():
         with pytest.raises(CtuError) as ei:
             ctucopy_amd.Engine(cfg)
         assert ei.value.code == ceng.CTU_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("cfg", [C1, C2, C3, C4, C5, "-fs 8000 -preset plpc".split(),
+                                 C2 + ["-fb_definition", "40filters"], C2 + ["-fb_shape", "rect", "-fb_definition", "12filters"],
+                                 C2 + ["-fb_definition", "100-4000Hz:1-10/10filters,4000-8000Hz:3-6/8filters"],
+                                 C2 + ["-w", "20", "-s", "5"], C2 + ["-fb_scale", "lin", "-fb_definition", "3filters"]])
+def test_phase2_chunk_tables_reproduce_the_filter_bank(cfg):
+    # the kernel's band-group / chunk tables, rebuilt into dense rows on the host, must equal the float bank exactly
+    cfg = [a for a in cfg if a not in ("-vad", "burg")]
+    err, nchunks, nslots = config_table(cfg, "phase2_check")
+    assert err == 0.0 and nchunks >= 1 and nslots >= 1
