@@ -248,9 +248,10 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     cf32 *ftab = as_const(p.ftab);
     for (int i = tid; i < p.tab_floats; i += WG) ltab[i] = p.ftab[i];
     for (int i = tid; i < 16 * LANEC; i += WG) ltw[(i / LANEC) * LTW_STRIDE + (i % LANEC)] = p.lanec[i];
-    // row padding (bins 257..259) is read by phase 2 under zero weights: start it finite; only finite values
-    // (transpose scratch) are ever written there afterwards
-    for (int i = tid; i < TILE * (PSTRIDE - 257); i += WG) Pt[(i / (PSTRIDE - 257)) * PSTRIDE + 257 + i % (PSTRIDE - 257)] = 0.f;
+    // Phase 2 reads whole 4-bin chunks, so bins a frame never writes (row padding 257..259; everything above bin
+    // 128 in the 256-point mode) are read under zero weights: start the tile finite.  Only finite values (spectra,
+    // transpose scratch) are ever written afterwards.
+    for (int i = tid; i < TILE * PSTRIDE; i += WG) Pt[i] = 0.f;
     __syncthreads();
     const float4 *lc = reinterpret_cast<const float4 *>(ltw + l16 * LTW_STRIDE);  // this lane's constant record
     const float4 *ltw4 = lc + (LC_TW >> 2);                                       // [0,8) stage twiddles, [8,12) untangle
