@@ -999,36 +999,72 @@ __global__ void vad_decide_kernel(const double *__restrict__ ci_all, const float
 }
 
 // TRAP-DCT (src/fea/fea_trap.cc:53-127): out[t][b*ndct+k] = sum_j G[k][j] * logmel[clamp(t-half+j)][b]
-// with mean removal, Hamming and REDFT10 folded into G on the host (rows of G sum to zero, so the centre
-// frame's value is subtracted first to keep the fp32 accumulation small).  One thread per (t, b).
-__global__ void trapdct_kernel(const float *__restrict__ logmel, float *__restrict__ rows, const float *__restrict__ G,
-                               const int4 *__restrict__ utt_info /* {row_off lo, row_off hi, T, -} */, int n_utt, int B,
-                               int traplen, int ndct, int D, const int *__restrict__ utt_of_chunk, int chunk) {
-    const int u = utt_of_chunk[blockIdx.x * 2];
-    const int tc = utt_of_chunk[blockIdx.x * 2 + 1];
+// with mean removal, Hamming and REDFT10 folded into G on the host.  Unlike the banded filter bank this IS a dense
+// contraction (ndct x traplen per band and frame), so it runs on the matrix cores: v_mfma_f32_16x16x4_f32 (exact
+// fp32 FMA chain), D[k][t] += G[k][4s..4s+3] * X[4s..4s+3][t] with the Toeplitz operand X[j][t] = x[t+j-half][b]
+// read straight from an LDS tile of log-mel frames.  Rows of G sum to zero, so each column is offset by its centre
+// value first (keeps the fp32 accumulation small).
+// One workgroup = 64 output frames of one utterance (4 waves x 16 frames), all bands.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NRB, int NSM>  // row blocks of 16 DCT coefficients (ndct <= 16*NRB); NSM >= ceil(traplen/4) tap groups
+__global__ __launch_bounds__(256) void trapdct_mfma_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
+                                                           const float *__restrict__ G, const int4 *__restrict__ utt_info,
+                                                           const int *__restrict__ chunk_tab, int B, int traplen, int ndct, int D) {
+    extern __shared__ float tile[];  // [64 + 4*nsteps][Bs]
+    const int u = chunk_tab[blockIdx.x * 2], tc = chunk_tab[blockIdx.x * 2 + 1];
     const int4 ui = utt_info[u];
     const int64_t r0 = ((int64_t)ui.y << 32) | (uint32_t)ui.x;
     const int T = ui.z;
-    const int half = (traplen - 1) / 2;
-    for (int e = threadIdx.x; e < chunk * B; e += blockDim.x) {
-        const int t = tc + e / B, b = e % B;
-        if (t >= T) continue;
-        float acc[32];
+    const int half = (traplen - 1) / 2, nsteps = (traplen + 3) / 4;
+    const int Bs = B | 1, nfr = 64 + 4 * (NSM <= 32 ? NSM : nsteps);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // log-mel tile with the first / last frame replicated beyond the utterance (src/fea/fea_trap.cc:64-70,111-127)
+    for (int e = tid; e < nfr * B; e += 256) {
+        const int f = e / B, b = e - f * B;
+        int t = tc - half + f;
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        tile[f * Bs + b] = logmel[(r0 + t) * B + b];
+    }
+    // this lane's slice of G: A[i = lane&15][k = lane>>4] of every 16x4 block
+    const int ai = lane & 15, ak = lane >> 4;
+    float areg[NRB][NSM];
 #pragma unroll
-        for (int k = 0; k < 32; k++) acc[k] = 0.f;
-        const float xc = logmel[(r0 + t) * B + b];
-        for (int j = 0; j < traplen; j++) {
-            int s = t - half + j;
-            s = s < 0 ? 0 : (s > T - 1 ? T - 1 : s);
-            const float x = logmel[(r0 + s) * B + b] - xc;
+    for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
-            for (int k = 0; k < 32; k++)
-                if (k < ndct) acc[k] += G[k * traplen + j] * x;
+        for (int s_ = 0; s_ < NSM; s_++) {
+            const int k = rb * 16 + ai, j = 4 * s_ + ak;
+            areg[rb][s_] = (s_ < nsteps && k < ndct && j < traplen) ? G[k * traplen + j] : 0.f;
         }
-        float *o = rows + (r0 + t) * D + b * ndct;
+    __syncthreads();
+    const int tl = wave * 16 + (lane & 15);  // local output frame of this lane's column
+    const int t_out = tc + tl;
+    for (int b = 0; b < B; b++) {
+        const float xc = tile[(tl + half) * Bs + b];
+        f32x4 acc[NRB];
 #pragma unroll
-        for (int k = 0; k < 32; k++)
-            if (k < ndct) o[k] = acc[k];
+        for (int rb = 0; rb < NRB; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < NSM; s_++) {
+            if (NSM <= 32 || s_ < nsteps) {  // exact instantiations run unguarded (A is zero beyond traplen)
+                const float bv = tile[(tl + 4 * s_ + ak) * Bs + b] - xc;
+#pragma unroll
+                for (int rb = 0; rb < NRB; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rb][s_], bv, acc[rb], 0, 0, 0);
+            }
+        }
+        if (t_out < T && ndct == 16 && NRB == 1 && (D & 3) == 0) {
+            // C/D layout: this lane holds coefficients 4*(lane>>4)..+3 of frame column lane&15: one 16-byte store
+            *reinterpret_cast<f32x4 *>(rows + (r0 + t_out) * D + b * 16 + ak * 4) = acc[0];
+        } else if (t_out < T) {
+            float *o = rows + (r0 + t_out) * D + b * ndct;
+#pragma unroll
+            for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = rb * 16 + ak * 4 + r;  // C/D layout: row = (lane>>4)*4 + reg, col = lane&15
+                    if (k < ndct) o[k] = acc[rb][r];
+                }
+        }
     }
 }
 
@@ -1145,6 +1181,8 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.kind == ctu::FeaKind::Dctc && d.nfea > MAXC) return "more cepstral coefficients than the kernel accumulates";
     if (d.B > 512) return "more than 512 filter bank channels";
     if (d.kind == ctu::FeaKind::TrapDct && o.fea_trapdct_ndct > 32) return "more than 32 TRAP DCT coefficients";
+    if (d.kind == ctu::FeaKind::TrapDct && o.fea_trapdct_traplen > 255) return "TRAP longer than 255 frames";
+    if (d.kind == ctu::FeaKind::TrapDct && (size_t)(64 + 256) * (d.B | 1) * 4 > 64 * 1024) return "too many bands for the TRAP tile";
     return "";
 }
 
@@ -1586,7 +1624,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     std::vector<int> uts(n_utt + 1, 0);
     std::vector<int4> uinfo(n_utt);
     std::vector<int> chunks;
-    const int trap_chunk = 8;
+    const int trap_chunk = 64;  // output frames per TRAP workgroup
     for (int i = 0; i < n_utt; i++) {
         const int64_t T = ctu_num_frames(e, utt_nsamples[i]);
         if (T < 0) {
@@ -1780,9 +1818,17 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             HIP_TRY(hipGetLastError());
         }
         if (d.kind == ctu::FeaKind::TrapDct) {
-            hipLaunchKernelGGL(trapdct_kernel, dim3(pl->n_trap_chunks), dim3(256), 0, s, e->logmel.p, d_rows, e->trapG.p,
-                               pl->utt_info.p, pl->n_utt, d.B, d.o.fea_trapdct_traplen, d.o.fea_trapdct_ndct, d.D,
-                               pl->trap_chunks.p, 8);
+            const int tl = d.o.fea_trapdct_traplen, nd = d.o.fea_trapdct_ndct;
+            const int ns = (tl + 3) / 4;
+            const size_t shm = (size_t)(64 + 4 * (ns <= 26 ? 26 : ns)) * (d.B | 1) * sizeof(float);
+#define TRAP_LAUNCH(NRB, NSM)                                                                                          \
+    hipLaunchKernelGGL((trapdct_mfma_kernel<NRB, NSM>), dim3(pl->n_trap_chunks), dim3(256), shm, s, e->logmel.p, d_rows, \
+                       e->trapG.p, pl->utt_info.p, pl->trap_chunks.p, d.B, tl, nd, d.D)
+            if (nd <= 16 && ns <= 26) TRAP_LAUNCH(1, 26);
+            else if (nd <= 16) TRAP_LAUNCH(1, 64);
+            else if (ns <= 26) TRAP_LAUNCH(2, 26);
+            else TRAP_LAUNCH(2, 64);
+#undef TRAP_LAUNCH
             HIP_TRY(hipGetLastError());
         }
     } catch (const std::exception &ex) {

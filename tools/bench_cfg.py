@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Times BASELINE.json configs other than the headline one (diagnostic; bench.py stays the contract)."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synth_arena
+from ctucopy_amd import Engine, shard
+from tests.util import C2, C3, C4, C4_NOVAD, C5
+
+CFGS = {"C2": C2, "C3": C3, "C4": C4, "C4_novad": C4_NOVAD, "C5": C5}
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", default="C3")
+ap.add_argument("--utts", type=int, default=2000)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+cfg = CFGS[a.cfg]
+eng = Engine(cfg)
+fs = eng.dims.fs
+lens = shard.utterance_lengths(a.utts, 7, lo=3 * fs, hi=15 * fs)
+plan = eng.plan(lens)
+dev = torch.device("cuda", 0)
+pcm = synth_arena(plan.total_samples, 1, dev)
+rows = torch.empty((plan.total_frames, eng.dims.row_floats), dtype=torch.float32, device=dev)
+vad = torch.empty(plan.total_frames, dtype=torch.uint8, device=dev) if eng.dims.has_vad else None
+for _ in range(2):
+    eng.run_device(plan, pcm, rows, vad=vad)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    eng.run_device(plan, pcm, rows, vad=vad)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+bpf = 2 * eng.dims.wshift + 4 * eng.dims.row_floats + (1 if eng.dims.has_vad else 0)
+print(json.dumps({"cfg": a.cfg, "frames": plan.total_frames, "ms_per_step": dt * 1e3, "frames_per_s": plan.total_frames / dt,
+                  "front_kernel_ms": eng.last_kernel_ms(), "bytes_per_frame": bpf,
+                  "hbm_frac": plan.total_frames * bpf / dt / 8e12}))
