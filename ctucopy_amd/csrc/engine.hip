@@ -790,211 +790,261 @@ struct VadParams {
     int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
 };
 
-// One workgroup (256 threads) per frame.
+// One wave per frame (4 frames per 256-thread workgroup): the frame's samples live in registers, strided over the
+// lanes (sample j = lane + 64 q), reductions are wave shuffles, no workgroup barrier inside the lattice.
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+#ifndef CTU_VAD_REAL
+#define CTU_VAD_REAL double  // arithmetic of the HC2R + Burg kernel (float was measured: see DESIGN.md)
+#endif
+typedef CTU_VAD_REAL vreal;
+__device__ __forceinline__ vreal wave_sum_r(vreal x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+template <int Q>  // samples per lane: window <= 64*Q
 __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
                                                        double *__restrict__ ci_out, VadParams vp, int64_t total_frames) {
-    __shared__ double hr[257], hi[257];      // halfcomplex input: Xa cos(phi), Xa sin(phi)   (vad.cc:227-230)
-    __shared__ double ef[512], eb[512], red[2][256];
-    __shared__ double tw_c[512], tw_s[512];
-    __shared__ double a[32], aa[32], cc[32];
-    const int64_t fr = blockIdx.x;
-    if (fr >= total_frames) return;
-    const int tid = threadIdx.x, K = vp.K, n = vp.wfft, W = vp.window, nc = vp.ncoef;
-    for (int i = tid; i < n; i += 256) {
-        double sv, cv;
-        sincos(2.0 * 3.14159265358979323846 * (double)i / (double)n, &sv, &cv);
-        tw_c[i] = cv;
-        tw_s[i] = sv;
-    }
-    for (int k = tid; k < K; k += 256) {
-        const float2 x = xri[fr * K + k];
-        const double xa = pnr[fr * K + k];
-        double c = 1.0, s_ = 0.0;  // Xph[0] = 0 (src/io/in.cc:398)
-        if (k > 0) {
-            const double mag = sqrt((double)x.x * x.x + (double)x.y * x.y);
-            if (mag > 0) {
-                c = x.x / mag;
-                s_ = x.y / mag;
-            } else {  // c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193); the last bin is 0 or pi by the sign of re (:399)
-                c = (k == K - 1) ? 1.0 : 0.0;
-                s_ = (k == K - 1) ? 0.0 : -1.0;
+    __shared__ vreal hr_s[4][260], hi_s[4][260];
+    __shared__ vreal a_s[4][32], aa_s[4][32], cc_s[4][32];  // lattice coefficients: lane 0 of each wave only
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = vp.K, n = vp.wfft, W = vp.window, nc = vp.ncoef;
+    const int64_t fr = (int64_t)blockIdx.x * 4 + wave;
+    const bool live = fr < total_frames;
+    vreal *hr = hr_s[wave], *hi = hi_s[wave];
+    if (live)
+        for (int k = lane; k < K; k += 64) {  // halfcomplex input: Xa cos(phi), Xa sin(phi)   (src/vad/vad.cc:227-230)
+            const float2 x = xri[fr * K + k];
+            const vreal xa = pnr[fr * K + k];
+            vreal c = 1.0, s_ = 0.0;  // Xph[0] = 0 (src/io/in.cc:398)
+            if (k > 0) {
+                const vreal mag = (vreal)sqrt((double)x.x * x.x + (double)x.y * x.y);
+                if (mag > 0) {
+                    c = x.x / mag;
+                    s_ = x.y / mag;
+                } else {  // c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193); the last bin is 0 or pi by the sign of re (:399)
+                    c = (k == K - 1) ? 1.0 : 0.0;
+                    s_ = (k == K - 1) ? 0.0 : -1.0;
+                }
+                if (k == K - 1) s_ = 0.0;
             }
-            if (k == K - 1) s_ = 0.0;
+            hr[k] = xa * c;
+            hi[k] = xa * s_;
         }
-        hr[k] = xa * c;
-        hi[k] = xa * s_;
-    }
-    __syncthreads();
+    __syncthreads();  // the only workgroup barrier: this wave's spectrum is in LDS
+    if (!live) return;
     // FFTW_HC2R, unnormalised: x_j = r0 + 2 sum_{k=1}^{n/2-1} (r_k cos(2 pi jk/n) - i_k sin(2 pi jk/n)) + (-1)^j r_{n/2}
-    for (int j = tid; j < W; j += 256) {
-        double acc = hr[0] + ((j & 1) ? -hr[K - 1] : hr[K - 1]);
-        for (int k = 1; k < K - 1; k++) {
-            const int m = (j * k) & (n - 1);
-            acc += 2.0 * (hr[k] * tw_c[m] - hi[k] * tw_s[m]);
+    // The twiddle exp(i 2 pi j k / n) of sample j advances by a fixed rotation per k: kept in registers (a table in
+    // LDS is read with stride k over the lanes and collides on the banks for every even k).
+    vreal ef[Q], eb[Q], wc[Q], ws[Q], rc_[Q], rs_[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int j = lane + 64 * q;
+        ef[q] = hr[0] + ((j & 1) ? -hr[K - 1] : hr[K - 1]);
+        { double sd, cd; sincos(2.0 * 3.14159265358979323846 * (double)j / (double)n, &sd, &cd); rs_[q] = (vreal)sd; rc_[q] = (vreal)cd; }
+        wc[q] = rc_[q];  // k = 1
+        ws[q] = rs_[q];
+    }
+    for (int k = 1; k < K - 1; k++) {
+        const vreal rk = 2.0 * hr[k], ik = 2.0 * hi[k];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            ef[q] += rk * wc[q] - ik * ws[q];
+            const vreal c2 = wc[q] * rc_[q] - ws[q] * rs_[q];
+            ws[q] = ws[q] * rc_[q] + wc[q] * rs_[q];
+            wc[q] = c2;
         }
-        ef[j] = eb[j] = acc;
     }
-    __syncthreads();
-    // Burg lattice (src/vdet/Burg.h:49-95)
-    double part = 0.0;
-    for (int j = tid; j < W; j += 256) part += ef[j] * ef[j];
-    red[0][tid] = part;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st) red[0][tid] += red[0][tid + st];
-        __syncthreads();
+    vreal part = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        if (lane + 64 * q >= W) ef[q] = 0.0;  // only the first `window` samples go to Burg (src/vad/vad.cc:233)
+        eb[q] = ef[q];
+        part += ef[q] * ef[q];
     }
-    double alpha = red[0][0] / (double)W;
-    __syncthreads();
-    if (tid == 0) a[0] = 1.0;
+    vreal alpha = wave_sum_r(part) / (vreal)W;
+    // Burg lattice (src/vdet/Burg.h:49-95); the coefficient recursion a[] / aa[] is kept by lane 0 in LDS
+    vreal *a = a_s[wave], *aa = aa_s[wave], *cc = cc_s[wave];
+    if (lane == 0) a[0] = 1.0;
     for (int ik = 1; ik < nc; ik++) {
-        double num = 0.0, den = 0.0;
-        for (int i = ik + tid; i < W; i += 256) {
-            den += ef[i] * ef[i] + eb[i - 1] * eb[i - 1];
-            num += ef[i] * eb[i - 1];
+        // eb[i-1]: the previous sample sits in the previous lane (or lane 63 of the previous q)
+        vreal ebm[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const vreal up = __shfl_up(eb[q], 1, 64);
+            const vreal wrap = q > 0 ? __shfl(eb[q > 0 ? q - 1 : 0], 63, 64) : 0.0;
+            ebm[q] = lane == 0 ? wrap : up;
         }
-        red[0][tid] = num;
-        red[1][tid] = den;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) {
-                red[0][tid] += red[0][tid + st];
-                red[1][tid] += red[1][tid + st];
+        vreal num = 0.0, den = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = lane + 64 * q;
+            if (i >= ik && i < W) {
+                den += ef[q] * ef[q] + ebm[q] * ebm[q];
+                num += ef[q] * ebm[q];
             }
-            __syncthreads();
         }
-        const double rc = -(2.0 * red[0][0]) / red[1][0];
+        num = wave_sum_r(num);
+        den = wave_sum_r(den);
+        const vreal rc = -(2.0 * num) / den;
         alpha *= 1.0 - rc * rc;
-        // filter the error signals: both updates use the old values
-        double nef[2], neb[2];
-        int cnt = 0;
-        for (int i = 1 + tid; i < W; i += 256) {
-            nef[cnt] = ef[i] + rc * eb[i - 1];
-            neb[cnt] = eb[i - 1] + rc * ef[i];
-            cnt++;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = lane + 64 * q;
+            if (i >= 1 && i < W) {  // both updates use the old values
+                const vreal nef = ef[q] + rc * ebm[q], neb = ebm[q] + rc * ef[q];
+                ef[q] = nef;
+                eb[q] = neb;
+            }
         }
-        __syncthreads();
-        cnt = 0;
-        for (int i = 1 + tid; i < W; i += 256) {
-            ef[i] = nef[cnt];
-            eb[i] = neb[cnt];
-            cnt++;
-        }
-        if (tid == 0) {
+        if (lane == 0) {
             a[ik] = rc;
             for (int i = 1; i < ik; i++) a[i] = aa[i] + rc * aa[ik - i];
             for (int i = 1; i <= ik; i++) aa[i] = a[i];
         }
-        __syncthreads();
     }
-    if (tid == 0) {  // Burg2Cepstrum (src/vdet/Burg.h:141-152)
+    if (lane == 0) {  // Burg2Cepstrum (src/vdet/Burg.h:141-152)
         for (int m = 1; m < nc; m++) {
-            double sum = 0.0;
+            vreal sum = 0.0;
             for (int k = 1; k < m; k++) sum += (m - k) * cc[m - k] * a[k];
             cc[m] = -a[m] - sum / m;
         }
-        cc[0] = log(alpha);
-        for (int m = 0; m < nc; m++) ci_out[fr * nc + m] = cc[m];
+        cc[0] = (vreal)log((double)alpha);
+        for (int m = 0; m < nc; m++) ci_out[fr * nc + m] = (double)cc[m];
     }
 }
 
-// One thread per utterance (src/vad/vad.cc:220-294 distance + background, :329-625 thresholds, vad.h:126-175 filter).
-__global__ void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
-                                  const float *__restrict__ rows, const int64_t *__restrict__ row_off,
-                                  int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per utterance (src/vad/vad.cc:220-294 distance + background, :329-625 thresholds, vad.h:126-175 filter).
+// The recurrences are sequential in t; the wave stages 64 frames of criterion inputs in LDS with coalesced loads,
+// then every lane replays them (same values in all lanes, lane 0 writes).
+__global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
+                                                         const float *__restrict__ rows, const int64_t *__restrict__ row_off,
+                                                         int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
+    __shared__ double stage[64 * 32];
+    __shared__ double c0[32];
+    const int u = blockIdx.x, lane = threadIdx.x;
     if (u >= n_utt) return;
     const int64_t r0 = row_off[u];
     const int T = (int)(row_off[u + 1] - r0);
-    const int nc = vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
-    double c0[32], ci[32];
+    const int nc = vp.cri == 0 ? 1 : vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
     int hist[33];
-    for (int i = 0; i < order; i++) hist[i] = 0;
-    int hidx = 0, nout = 0;
+#pragma unroll
+    for (int i = 0; i < 33; i++) hist[i] = 0;
+    int hidx = 0, nout = 0, nsum = 0;
     double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
     int adapt_vad = 0;
-    for (int t = 0; t < T; t++) {
-        double cri;
+    for (int tb = 0; tb < T; tb += 64) {
+        const int nt = min(64, T - tb);
+        __syncthreads();
         if (vp.cri == 0) {
-            double en = cri_energy[r0 + t];
-            if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
-            cri = en;
-        } else {
-            if (vp.cri == 1) {
-                for (int i = 0; i < nc; i++) ci[i] = ci_all[(r0 + t) * nc + i];
-            } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131)
-                const float *row = rows + (r0 + t) * vp.D;
-                ci[0] = vp.c0_slot >= 0 ? (double)row[vp.c0_slot] : 0.0;
-                for (int i = 1; i < nc; i++) ci[i] = row[i - 1];
+            if (lane < nt) stage[lane] = cri_energy[r0 + tb + lane];
+        } else if (vp.cri == 1) {
+            for (int e = lane; e < nt * nc; e += 64) stage[e] = ci_all[(r0 + tb) * nc + e];
+        } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131)
+            for (int e = lane; e < nt * nc; e += 64) {
+                const int f = e / nc, i = e - f * nc;
+                const float *row = rows + (r0 + tb + f) * vp.D;
+                stage[e] = i == 0 ? (vp.c0_slot >= 0 ? (double)row[vp.c0_slot] : 0.0) : (double)row[i - 1];
             }
-            if (t == 0) {
-                for (int i = 0; i < nc; i++) c0[i] = ci[i];
+        }
+        __syncthreads();
+        for (int tt = 0; tt < nt; tt++) {
+            const int t = tb + tt;
+            const double *ci = stage + tt * nc;
+            double cri;
+            if (vp.cri == 0) {
+                double en = ci[0];
+                if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
+                cri = en;
+            } else if (t == 0) {
+                if (lane < nc) c0[lane] = ci[lane];
+                __syncthreads();
                 cri = 0.0;
             } else {
-                if (t == 1)
-                    for (int i = 0; i < nc; i++) c0[i] = (c0[i] + ci[i]) / 2.0;
+                if (t == 1) {
+                    if (lane < nc) c0[lane] = (c0[lane] + ci[lane]) / 2.0;
+                    __syncthreads();
+                }
                 double sum = 0.0;
                 for (int i = 1; i < nc; i++) sum += (ci[i] - c0[i]) * (ci[i] - c0[i]);
                 cri = 4.3429 * sqrt(2 * sum);
             }
-        }
-        int vad0;
-        if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
-        else if (vp.thr == 1) {
-            if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
-            else {
-                crimin = cri < crimin ? cri : crimin;
-                crimax = cri > crimax ? cri : crimax;
-            }
-            vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
-        } else if (vp.thr == 2) {
-            if (t == 0) {
-                crimean = cri;
-                crimean2 = cri * cri;
-                crivar = 0.0;
-                adapt_vad = 0;
-            } else {
-                const double thr = crimean + vp.adapt_za * sqrt(crivar);
-                if (cri < thr || t <= vp.adapt_init) {
-                    crimean = vp.adapt_q * crimean + (1.0 - vp.adapt_q) * cri;
-                    crimean2 = vp.adapt_q * crimean2 + (1.0 - vp.adapt_q) * cri * cri;
-                    crivar = crimean2 - crimean * crimean;
+            int vad0;
+            if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
+            else if (vp.thr == 1) {
+                if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
+                else {
+                    crimin = cri < crimin ? cri : crimin;
+                    crimax = cri > crimax ? cri : crimax;
+                }
+                vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
+            } else if (vp.thr == 2) {
+                if (t == 0) {
+                    crimean = cri;
+                    crimean2 = cri * cri;
+                    crivar = 0.0;
                     adapt_vad = 0;
-                } else adapt_vad = 1;
-            }
-            vad0 = adapt_vad;
-        } else {
-            const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
-            if (t < init) {
-                dmax = dmin = cri;
-                vad0 = 0;
-            } else if (t == init) {
-                dmax = (cri > dmax ? cri : dmax) + vp.dyn_min / 10.0;
-                dmin = (cri < dmin ? cri : dmin) - vp.dyn_min / 10.0;
-                vad0 = 0;
+                } else {
+                    const double thr = crimean + vp.adapt_za * sqrt(crivar);
+                    if (cri < thr || t <= vp.adapt_init) {
+                        crimean = vp.adapt_q * crimean + (1.0 - vp.adapt_q) * cri;
+                        crimean2 = vp.adapt_q * crimean2 + (1.0 - vp.adapt_q) * cri * cri;
+                        crivar = crimean2 - crimean * crimean;
+                        adapt_vad = 0;
+                    } else adapt_vad = 1;
+                }
+                vad0 = adapt_vad;
             } else {
-                dmax = dmax < cri ? vp.qmaxinc * dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * dmax + (1.0 - vp.qmaxdec) * cri;
-                dmin = dmin > cri ? vp.qmindec * dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * dmin + (1.0 - vp.qmininc) * cri;
-                const double dyn = dmax - dmin;
-                vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
+                const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
+                if (t < init) {
+                    dmax = dmin = cri;
+                    vad0 = 0;
+                } else if (t == init) {
+                    dmax = (cri > dmax ? cri : dmax) + vp.dyn_min / 10.0;
+                    dmin = (cri < dmin ? cri : dmin) - vp.dyn_min / 10.0;
+                    vad0 = 0;
+                } else {
+                    dmax = dmax < cri ? vp.qmaxinc * dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * dmax + (1.0 - vp.qmaxdec) * cri;
+                    dmin = dmin > cri ? vp.qmindec * dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * dmin + (1.0 - vp.qmininc) * cri;
+                    const double dyn = dmax - dmin;
+                    vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
+                }
             }
-        }
-        if (vp.cri != 0 && !(vad0 && t > vp.cep_init))
-            for (int i = 0; i < nc; i++) c0[i] = vp.cep_p * c0[i] + (1.0 - vp.cep_p) * ci[i];
-        hist[hidx] = vad0;
-        hidx = (hidx + 1) % order;
-        if (t >= h) {
-            int sum = 0;
-            for (int i = 0; i < order; i++) sum += hist[i];
-            vad_out[r0 + nout++] = ((double)sum / (double)order >= 0.5) ? '1' : '0';
+            if (vp.cri != 0 && !(vad0 && t > vp.cep_init)) {  // background update (src/vad/vad.cc:288-294)
+                __syncthreads();
+                if (lane < nc) c0[lane] = vp.cep_p * c0[lane] + (1.0 - vp.cep_p) * ci[lane];
+                __syncthreads();
+            }
+            // majority filter over the last `order` raw decisions (running count instead of re-summing)
+            int old = 0;
+#pragma unroll
+            for (int i = 0; i < 33; i++) old = (i == hidx) ? hist[i] : old;
+#pragma unroll
+            for (int i = 0; i < 33; i++) hist[i] = (i == hidx) ? vad0 : hist[i];
+            nsum += vad0 - old;
+            hidx = (hidx + 1 == order) ? 0 : hidx + 1;
+            if (t >= h) {
+                if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
+                nout++;
+            }
         }
     }
     for (int k = 0; k < h && nout < T; k++) {  // flush: zeros pushed (src/vad/vad.h:156-175)
-        hist[hidx] = 0;
-        hidx = (hidx + 1) % order;
-        int sum = 0;
-        for (int i = 0; i < order; i++) sum += hist[i];
-        vad_out[r0 + nout++] = ((double)sum / (double)order >= 0.5) ? '1' : '0';
+        int old = 0;
+#pragma unroll
+        for (int i = 0; i < 33; i++) old = (i == hidx) ? hist[i] : old;
+#pragma unroll
+        for (int i = 0; i < 33; i++) hist[i] = (i == hidx) ? 0 : hist[i];
+        nsum -= old;
+        hidx = (hidx + 1 == order) ? 0 : hidx + 1;
+        if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
+        nout++;
     }
 }
 
@@ -1810,10 +1860,14 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         }
 #endif
         if (e->do_vad) {
-            if (e->vp.cri == 1)
-                hipLaunchKernelGGL(vad_burg_kernel, dim3((unsigned)pl->total_frames), dim3(256), 0, s, pl->xri.p, pl->pnr.p,
-                                   pl->vad_ci.p, e->vp, pl->total_frames);
-            hipLaunchKernelGGL(vad_decide_kernel, dim3((pl->n_utt + 63) / 64), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
+            if (e->vp.cri == 1) {
+                const dim3 g((unsigned)((pl->total_frames + 3) / 4));
+                if (d.window <= 256)
+                    hipLaunchKernelGGL(vad_burg_kernel<4>, g, dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames);
+                else
+                    hipLaunchKernelGGL(vad_burg_kernel<8>, g, dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames);
+            }
+            hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
                                pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
             HIP_TRY(hipGetLastError());
         }
