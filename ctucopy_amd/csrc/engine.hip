@@ -663,7 +663,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
                 acc += acc1;
                 float y = acc;
-                if (p.fb_inld) y = __powf(y, 0.33f);  // src/fea/fb.cc:81-83
+                if (p.fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
                 // v_log_f32 (log2, ~1 ulp) * ln 2: band energies of int16 speech are far from the denormal range
                 if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __builtin_amdgcn_logf(y) * 0.69314718056f;
                 if (p.e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
@@ -707,24 +707,26 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     // c[k] = R[k], the autocorrelation by cosine iDFT (src/fea/fea_impl.cc:181-198); every lane of the
                     // frame runs Levinson-Durbin in double (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
                     // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
+                    // fp32: with the cube-root (or squared) band energies the autocorrelation matrix is well
+                    // conditioned; measured deviation from a double recursion ~1e-6 (tests/test_gpu_parity.py::test_c3_plp)
                     const int P_ = p.lporder;
-                    double a[MAX_LP + 1], cc[MAX_LP + 1];
-                    const double r0 = c[0];
-                    if (p.e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = (float)log(r0);  // E = ln R[0] (src/fea/fea_impl.cc:177)
-                    double rc = -(double)c[1] / r0;
-                    double err = r0 * (1 - rc * rc);
+                    float a[MAX_LP + 1], cc[MAX_LP + 1];
+                    const float r0 = c[0];
+                    if (p.e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = __builtin_amdgcn_logf(r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
+                    float rc = -c[1] / r0;
+                    float err = r0 * (1 - rc * rc);
                     a[0] = 1;
                     a[1] = rc;
 #pragma unroll
                     for (int ik = 2; ik <= MAX_LP; ik++) {
                         if (ik <= P_) {
-                            double dm = c[ik];
+                            float dm = c[ik];
 #pragma unroll
-                            for (int n = 1; n < ik; n++) dm += a[n] * (double)c[ik - n];
+                            for (int n = 1; n < ik; n++) dm += a[n] * c[ik - n];
                             rc = -dm / err;
 #pragma unroll
                             for (int n = 1; n <= ik / 2; n++) {
-                                const double lo = a[n], hi = a[ik - n];
+                                const float lo = a[n], hi = a[ik - n];
                                 a[n] = lo + rc * hi;
                                 if (n != ik - n) a[ik - n] = hi + rc * lo;
                             }
@@ -735,26 +737,26 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     if (p.lp_is_lpa) {
 #pragma unroll
                         for (int i = 1; i <= MAX_LP; i++)
-                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = (float)a[i];
+                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = a[i];
                     } else {
-                        cc[0] = log(err);
+                        cc[0] = __builtin_amdgcn_logf(err) * 0.69314718056f;
 #pragma unroll
                         for (int n = 1; n <= MAX_LP; n++) {
                             if (n <= p.ncep) {
-                                double sum = 0;
+                                float sum = 0;
 #pragma unroll
                                 for (int k = 1; k < n; k++)
-                                    if (k <= P_) sum += (n - k) * cc[n - k] * a[k];
-                                cc[n] = (n <= P_ ? -a[n] : 0.0) - sum / n;
+                                    if (k <= P_) sum += (float)(n - k) * cc[n - k] * a[k];
+                                cc[n] = (n <= P_ ? -a[n] : 0.0f) - sum / (float)n;
                             }
                         }
 #pragma unroll
                         for (int n = 0; n <= MAX_LP; n++) {
                             if (n <= p.ncep) {
-                                double val = cc[n];
-                                if (n >= 1 && p.lifter_on) val *= (double)ftab[p.lift_off + n - 1];
+                                float val = cc[n];
+                                if (n >= 1 && p.lifter_on) val *= ftab[p.lift_off + n - 1];
                                 const int slot = row_slot[n];
-                                if (slot >= 0 && fvalid && g == (n & 7)) orow[slot] = (float)val;
+                                if (slot >= 0 && fvalid && g == (n & 7)) orow[slot] = val;
                             }
                         }
                     }
