@@ -558,15 +558,18 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     // H = Navg / (Navg^a + Yavg^a)^(1/a); the output X - H X is formed as X (1 - H) with 1 - H written
                     // without cancellation (fp32 here, double in the reference; double was measured: no accuracy gain,
                     // -15 % on the main path through register allocation)
+                    // (v_rcp_f32 / v_rsq_f32, ~1 ulp, instead of IEEE division and square root: this loop is a serial chain)
                     float H, omH;
                     if (p.nr_a == 1.0f) {
-                        const float r = navg + yavg;
-                        H = navg / r;
-                        omH = yavg / r;
+                        const float ir = __builtin_amdgcn_rcpf(navg + yavg);
+                        H = navg * ir;
+                        omH = yavg * ir;
                     } else if (p.nr_a == 2.0f) {
-                        const float r = sqrtf(navg * navg + yavg * yavg);
-                        H = navg / r;
-                        omH = (yavg * yavg) / (r * (r + navg));
+                        const float r2 = navg * navg + yavg * yavg;
+                        const float ir = __builtin_amdgcn_rsqf(r2);
+                        const float r = r2 * ir;
+                        H = navg * ir;
+                        omH = (yavg * yavg) * __builtin_amdgcn_rcpf(r * (r + navg));
                     } else {
                         H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
                         omH = 1.0f - H;
