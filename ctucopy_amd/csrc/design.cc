@@ -294,7 +294,24 @@ Design::Design(const Opts &opts) : o(opts) {
         if (o.fea_E) e_slot = (o.fea_c0 && kind != FeaKind::Lpa) ? nfea : ncep;
     }
     if (o.fea_E) size++;
-    D = size;
+    Dbase = D = size;
+    if (o.fea_delta || o.fea_trap) {
+        // BATCH::init_delta (src/io/batch.cc:122-130): n_order chained deltaFEA stages, each sized on
+        // fea_c = fea_ncepcoefs+1 (src/fea/fea_delta.cc:22-28); OUT then sees fea_c*(n_order+1) values, or
+        // fea_c*(2*d_win+1) for -fea_trap, plus E (src/io/out.cc:95-113 with Xsize of the last stage).
+        const int fea_c = ncep + 1;
+        post_order = o.n_order;
+        post_stack = o.fea_trap;
+        post_w[0] = o.d_win; post_w[1] = o.a_win; post_w[2] = o.t_win;
+        for (int j = 0; j < post_order; j++)
+            if (post_w[j] < 1) throw DesignError(o.fea_trap ? "FEA: Trap window size must be >= 3!" : "FEA: Delta window size must be > 1!");
+        if (post_order > 0) {
+            int xs = post_stack ? fea_c * (2 * o.d_win + 1) : fea_c * (post_order + 1);
+            if ((kind == FeaKind::Lpc || kind == FeaKind::Dctc) && !o.fea_c0) xs--;
+            if (kind == FeaKind::Lpa) xs--;
+            D = xs + (o.fea_E ? 1 : 0);
+        }
+    }
     if (D > 32767) throw DesignError("OUT: HTK format does not support more than 32767 features!");
     period = (unsigned)std::floor(.5 + 10000000. * wshift / (double)o.fs);
     int kcode = 9;
@@ -304,6 +321,9 @@ Design::Design(const Opts &opts) : o(opts) {
     else if (kind == FeaKind::LogSpec) kcode = 7;
     if (o.fea_c0) kcode |= 020000;
     if (o.fea_E) kcode |= 000100;
+    if (o.fea_delta && o.n_order >= 1) kcode |= 000400;   // src/io/out.cc:157-159 (-fea_trap sets both fields too)
+    if (o.fea_delta && o.n_order >= 2) kcode |= 001000;
+    if (o.fea_delta && o.n_order == 3) kcode |= 0100000;
     htk_kind = kcode;
 }
 

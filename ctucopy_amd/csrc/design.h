@@ -9,6 +9,7 @@
 //   cosine iDFT for LPC       src/fea/fea_impl.cc:141-198
 //   TRAP Hamming / REDFT10    src/fea/fea_trap.cc:20-107
 //   output geometry           src/io/out.cc:95-113,145-171
+//   delta / stacking chain    src/io/batch.cc:122-130, src/fea/fea_delta.cc:20-60 (geometry only)
 #pragma once
 
 #include <string>
@@ -30,6 +31,10 @@ struct Design {
     FeaKind kind = FeaKind::Dctc;
     int nfea = 0;      // internal feature vector length (fvec)
     int D = 0;         // floats per output row
+    int Dbase = 0;     // floats per row as the front end writes it (== D unless a delta / stacking chain follows)
+    int post_order = 0;        // number of chained deltaFEA stages (0 = none; -fea_trap: 1)
+    bool post_stack = false;   // -fea_trap: the single stage stacks 2*d_win+1 frames instead of differentiating
+    int post_w[3] = {0, 0, 0}; // window half-width of each stage (d_win, a_win, t_win)
     int htk_kind = 0;  // HTK parameter kind incl. qualifier bits
     unsigned period = 0;
 

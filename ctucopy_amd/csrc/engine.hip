@@ -1160,6 +1160,109 @@ struct DevBuf {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row N1: the deltaFEA chain (src/fea/fea_delta.cc, wired by src/io/batch.cc:122-130,172-192,251-291) and the
+// writers' block layout (src/io/out.cc:188-201), as one pass over the base rows of a 64-frame chunk.
+//
+// The reference streams frames through a ring per stage; what that ring computes is (tests/test_oracle_delta.py
+// holds the oracle's replay of the ring against exactly these formulas):
+//   stage k, window w:   y[t] = sum_{i=1..w} i * (x[min(t+i,T-1)] - x[max(t-i,0)]) / (2 sum i^2),
+//                        except that a stage with w == 1 emits y[T-1] = 0 (its flush writes the last frame twice);
+//   x of stage k+1 is y of stage k (clamping applies to the frame index of y, not to a virtual y beyond the edge);
+//   row[t] = [x | y1 | y2 | y3] in the base block order (c1..cN, c0), then E of frame min(t + sum w, T-1) - the
+//            writers read E through a pointer, so it belongs to the newest frame fed in;
+//   -fea_trap (stack): X[i*L+j] = fvec_i of frame clamp(t-w+j) with L = 2w+1, fvec order (c0, c1..cN); the first
+//            row uses frames (0 x w, 1, 1, 2..w) and, for w == 1, the last row uses frame T-1 three times; rows 0 and
+//            T-w..T-1 then get X[0..fea_c) overwritten by the centre frame's fvec (fea_delta.cc:88-90,196-198).
+// HBM-bound: reads Dbase floats (+ halo) and writes D floats per frame, both fully coalesced (a chunk's rows are
+// contiguous); LDS holds the levels of the chain for 64 + 2*halo frames.
+struct PostParams {
+    int fea_c, Dbase, D, order, stack, has_e;
+    int w[3];
+    float inv_den[3];
+};
+
+__global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ base, float *__restrict__ rows,
+                                                   const int4 *__restrict__ utt_info, const int *__restrict__ chunks,
+                                                   const PostParams pp) {
+    extern __shared__ float psm[];
+    const int u = chunks[2 * blockIdx.x], t0 = chunks[2 * blockIdx.x + 1];
+    const int4 ui = utt_info[u];
+    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+    const int T = ui.z;
+    const int fc = pp.fea_c, Db = pp.Dbase, D = pp.D;
+    const int H = pp.stack ? pp.w[0] : pp.w[0] + (pp.order > 1 ? pp.w[1] : 0) + (pp.order > 2 ? pp.w[2] : 0);
+    const int tlo = t0 - H, R = 64 + 2 * H;
+    const int nout = min(64, T - t0);
+    float *x0 = psm;                        // [R][Db]   base rows (E column included)
+    float *lv = psm + (size_t)R * Db;       // levels 1..order: [R][fc] each
+    // level 0: the contiguous run of base rows this chunk touches
+    {
+        const int flo = max(tlo, 0), fhi = min(t0 + 63 + H, T - 1);
+        const float *src = base + (ro + flo) * Db;
+        float *dst = x0 + (size_t)(flo - tlo) * Db;
+        const int n = (fhi - flo + 1) * Db;
+        for (int e = threadIdx.x; e < n; e += 256) dst[e] = src[e];
+    }
+    __syncthreads();
+    auto rowof = [&](int f) { return min(max(f, 0), T - 1) - tlo; };
+    if (pp.stack) {
+        const int w = pp.w[0], L = 2 * w + 1, xs = fc * L;
+        for (int e = threadIdx.x; e < nout * D; e += 256) {
+            const int tt = e / D, k = e - tt * D, t = t0 + tt;
+            float v;
+            if (k == xs) v = x0[(size_t)rowof(t + w) * Db + fc];  // E
+            else {
+                int i, f;
+                if (k < fc && (t == 0 || t >= T - w)) { i = k; f = t; }
+                else {
+                    i = k / L;
+                    const int j = k - i * L;
+                    if (t == 0) f = j < w ? 0 : max(1, j - w);
+                    else if (w == 1 && t == T - 1) f = T - 1;
+                    else f = t - w + j;
+                }
+                v = x0[(size_t)rowof(f) * Db + (i == 0 ? fc - 1 : i - 1)];
+            }
+            rows[(ro + t0) * D + e] = v;
+        }
+        return;
+    }
+    int hk = H;
+    const float *prev = x0;
+    int pstride = Db;
+    for (int k = 0; k < pp.order; k++) {
+        const int w = pp.w[k];
+        hk -= w;  // halo this level still needs for the stages after it
+        float *cur = lv + (size_t)k * R * fc;
+        const int flo = max(t0 - hk, 0), fhi = min(t0 + 63 + hk, T - 1);
+        const int n = (fhi - flo + 1) * fc;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int ff = e / fc, c = e - ff * fc, f = flo + ff;
+            float acc = 0.f;
+            for (int i = 1; i <= w; i++) acc += (float)i * (prev[(size_t)rowof(f + i) * pstride + c] - prev[(size_t)rowof(f - i) * pstride + c]);
+            acc *= pp.inv_den[k];
+            if (w == 1 && f == T - 1) acc = 0.f;
+            cur[(size_t)(f - tlo) * fc + c] = acc;
+        }
+        __syncthreads();
+        prev = cur;
+        pstride = fc;
+    }
+    const int xs = fc * (pp.order + 1);
+    for (int e = threadIdx.x; e < nout * D; e += 256) {
+        const int tt = e / D, k = e - tt * D, t = t0 + tt;
+        float v;
+        if (k == xs) v = x0[(size_t)rowof(t + H) * Db + fc];  // E
+        else {
+            const int j = k / fc, c = k - j * fc;
+            v = j == 0 ? x0[(size_t)(t - tlo) * Db + c] : lv[((size_t)(j - 1) * R + (t - tlo)) * fc + c];
+        }
+        rows[(ro + t0) * D + e] = v;
+    }
+}
+
+
 struct ctu_engine {
     std::unique_ptr<ctu::Design> design;
     int device = 0;
@@ -1175,6 +1278,7 @@ struct ctu_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
+    DevBuf<float> base_rows;  // front-end rows ahead of the delta / stacking pass, sized by the largest plan seen
     DevBuf<unsigned long long> stamps;
     bool do_vad = false;
     VadParams vp;
@@ -1213,7 +1317,17 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.nr_mode != "none" && o.nr_mode != "exten") return "nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221)";
     if (o.nr_when_afterFB) return "-nr_when afterFB";
     if (o.rasta) return "-nr_rasta";
-    if (o.fea_delta || o.fea_trap) return "delta / stacked features (next row N1)";
+    if (d.post_order > 0) {
+        if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "delta / stacking on non-cepstral kinds (the reference sizes the chain as fea_ncepcoefs+1, src/fea/fea_delta.cc:22-28)";
+        if (!o.fea_c0) return "delta / stacking without -fea_c0 (the reference's writers leave slots of the row unwritten, src/io/out.cc:190-201)";
+        if (o.do_vad()) return "VAD together with delta / stacking (the detector would run on delayed and on flushed frames)";
+        int wsum = 0;
+        for (int j = 0; j < d.post_order; j++) {
+            if (d.post_w[j] > 16) return "delta / stacking window above 16 frames";
+            wsum += d.post_w[j];
+        }
+        if (wsum > 24) return "delta windows adding up to more than 24 frames (LDS tile of the chain)";
+    }
     if (o.stat_cmvn || o.apply_cmvn || o.fea_Z_exp > 0 || o.fea_Z_block > 0) return "CMVN / CMS (next row N2)";
     if (o.fea_E && d.kind == ctu::FeaKind::TrapDct) return "-fea_E with trapdct (the energy lags the features by 50 frames in the reference)";
     if (o.do_vad()) {
@@ -1686,6 +1800,17 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             set_error(e, "IO: Signal shorter than one frame!");  // src/io/in.cc:277
             return CTU_ERR_INPUT;
         }
+        if (d.post_order > 0 && T > 0) {
+            int wmax = 0;
+            for (int j = 0; j < d.post_order; j++) wmax = std::max(wmax, d.post_w[j]);
+            // With exactly window+1 frames a stage never takes its steady-state branch, so its flush starts from ring
+            // slot 0 instead of the oldest slot and the emitted rows mix frames (src/fea/fea_delta.cc:118,183-186);
+            // with fewer it reads slots that were never written.  Neither is a feature worth reproducing.
+            if (T < wmax + 2) {
+                set_error(e, "ENGINE: delta / stacking on fewer than window+2 frames is ill-defined in the reference (src/fea/fea_delta.cc:74-130,178-206)");
+                return CTU_ERR_INPUT;
+            }
+        }
         if (d.kind == ctu::FeaKind::TrapDct && T > 0 && T < (d.o.fea_trapdct_traplen + 1) / 2) {
             set_error(e, "ENGINE: trapdct on fewer than (traplen+1)/2 frames is undefined in the reference (src/fea/fea_trap.cc:64-70)");
             return CTU_ERR_INPUT;
@@ -1754,12 +1879,13 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
                 pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
-        if (d.kind == ctu::FeaKind::TrapDct) {
+        if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
             pl->n_trap_chunks = (int)chunks.size() / 2;
-            if (e->logmel.n < (size_t)ro * d.B) e->logmel.alloc((size_t)ro * d.B);
         }
+        if (d.kind == ctu::FeaKind::TrapDct && e->logmel.n < (size_t)ro * d.B) e->logmel.alloc((size_t)ro * d.B);
+        if (d.post_order > 0 && e->base_rows.n < (size_t)ro * d.Dbase) e->base_rows.alloc((size_t)ro * d.Dbase);
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
@@ -1788,7 +1914,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         KParams kp;
         std::memset(&kp, 0, sizeof kp);
         kp.pcm = d_pcm;
-        kp.rows = d_rows;
+        kp.rows = d.post_order > 0 ? e->base_rows.p : d_rows;
         kp.logmel = e->logmel.p;
         kp.xri = pl->xri.p;
         kp.pnr = pl->pnr.p;
@@ -1820,7 +1946,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.wshift = d.wshift;
         kp.B = d.B;
         kp.nfea = d.nfea;
-        kp.D = d.D;
+        kp.D = d.Dbase;
         kp.ncep = d.o.fea_ncepcoefs;
         kp.lporder = d.o.fea_lporder;
         kp.lift_off = e->lift_off;
@@ -1888,6 +2014,29 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             else if (ns <= 26) TRAP_LAUNCH(2, 26);
             else TRAP_LAUNCH(2, 64);
 #undef TRAP_LAUNCH
+            HIP_TRY(hipGetLastError());
+        }
+        if (d.post_order > 0) {
+            PostParams pp;
+            std::memset(&pp, 0, sizeof pp);
+            pp.fea_c = d.o.fea_ncepcoefs + 1;
+            pp.Dbase = d.Dbase;
+            pp.D = d.D;
+            pp.order = d.post_order;
+            pp.stack = d.post_stack ? 1 : 0;
+            pp.has_e = d.o.fea_E ? 1 : 0;
+            int H = 0;
+            for (int j = 0; j < d.post_order; j++) {
+                pp.w[j] = d.post_w[j];
+                int den = 0;
+                for (int i = 1; i <= d.post_w[j]; i++) den += i * i;
+                pp.inv_den[j] = (float)(1.0 / (2.0 * den));
+                H += d.post_w[j];
+            }
+            const int R = 64 + 2 * H;
+            const size_t shm = ((size_t)R * d.Dbase + (size_t)(d.post_stack ? 0 : d.post_order) * R * pp.fea_c) * sizeof(float);
+            hipLaunchKernelGGL(post_kernel, dim3(pl->n_trap_chunks), dim3(256), shm, s, e->base_rows.p, d_rows,
+                               pl->utt_info.p, pl->trap_chunks.p, pp);
             HIP_TRY(hipGetLastError());
         }
     } catch (const std::exception &ex) {

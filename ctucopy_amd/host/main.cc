@@ -377,7 +377,13 @@ int real_main(int argc, char **argv) {
             }
             if (ark) ark->add(it.fout, rows[i].data(), nr, d.row_floats);
             else if (pf) pf->add(rows[i].data(), nr, d.row_floats);
-            else write_htk(it.fout, rows[i].data(), nr, d);
+            else {
+                // -fea_trap: the reference's writers overwrite fea_kind with "spec" when they save their first frame
+                // (src/io/out.cc:182), so every header after the first file carries base kind 8 (out.cc:146-152).
+                ctu_dims dh = d;
+                if (o.fea_trap && pos + i > 0) dh.htk_kind = (d.htk_kind & ~077) | 8;
+                write_htk(it.fout, rows[i].data(), nr, dh);
+            }
         }
         pos = end;
     }

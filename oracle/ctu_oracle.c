@@ -76,6 +76,9 @@ struct ctuo {
     double *ut_re, *ut_im; /* untangle twiddles exp(-2 pi i k / n), k<=n/4.. */
     /* geometry */
     int nfea, D, htk_kind;
+    int post_order;     /* 0 = none, 1..3 = delta stages chained after FEA (batch.cc:122-130) */
+    int post_stack;     /* -fea_trap: one stage that stacks 2*d_win+1 frames (fea_delta.cc:166-176) */
+    int Xsize;          /* size of the vector OUT sees: nfea, fea_c*(n_order+1) or fea_c*(2*d_win+1) */
     unsigned period;
     int do_vad;
     /* debug taps */
@@ -712,9 +715,19 @@ static int design_all(ctuo_t *c) {
         set_err(c, "oracle: nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221); not restated");
         return -1;
     }
-    if (o->fea_delta || o->fea_trap || o->stat_cmvn || o->apply_cmvn || o->fea_Z_exp > 0 || o->fea_Z_block > 0) {
-        set_err(c, "oracle: delta / CMVN / CMS post-processing is outside the restated path");
+    if (o->stat_cmvn || o->apply_cmvn || o->fea_Z_exp > 0 || o->fea_Z_block > 0) {
+        set_err(c, "oracle: CMVN / CMS post-processing is outside the restated path");
         return -1;
+    }
+    if (o->fea_delta || o->fea_trap) { /* row N1: restated for the layouts the reference writes completely */
+        if (strcmp(o->fea_kind, "dctc") && strcmp(o->fea_kind, "lpc")) {
+            set_err(c, "oracle: delta / stacking on non-cepstral kinds is not restated (deltaFEA sizes its vectors as fea_ncepcoefs+1, fea_delta.cc:22-28)");
+            return -1;
+        }
+        if (!o->fea_c0) {
+            set_err(c, "oracle: delta / stacking without -fea_c0 is not restated (the writers leave slots of the row unwritten, out.cc:190-201)");
+            return -1;
+        }
     }
     /* Hamming, src/io/in.cc:139-144 (alpha = 0.54, in.cc:206) */
     c->W = malloc(sizeof(double) * o->window);
@@ -758,7 +771,19 @@ static int design_all(ctuo_t *c) {
     }
     /* output geometry, src/io/out.cc:95-113 (htkOUT::get_fea_size), 146-159 */
     if ((!strcmp(k, "lpa") || !strcmp(k, "spec") || !strcmp(k, "logspec")) && o->fea_c0) o->fea_c0 = 0;
-    int size = c->nfea;
+    c->post_order = 0; c->post_stack = 0; c->Xsize = c->nfea;
+    if (o->fea_delta || o->fea_trap) {
+        /* BATCH::init_delta, batch.cc:122-130; deltaFEA ctor, fea_delta.cc:20-60 */
+        int fea_c = o->fea_ncepcoefs + 1;
+        c->post_order = o->n_order;
+        c->post_stack = o->fea_trap ? 1 : 0;
+        int w[3] = { o->d_win, o->a_win, o->t_win };
+        for (int j = 0; j < o->n_order; j++)
+            if (w[j] < 1) { set_err(c, o->fea_trap ? "FEA: Trap window size must be >= 3!" : "FEA: Delta window size must be > 1!"); return -1; }
+        c->Xsize = o->fea_trap ? fea_c * (2 * o->d_win + 1) : fea_c * (o->n_order + 1);
+        if (c->do_vad) { set_err(c, "oracle: VAD together with delta / stacking is not restated (the detector would run on delayed and on flushed frames, batch.cc:230-241,251-291)"); return -1; }
+    }
+    int size = c->Xsize;
     if (!strcmp(k, "lpa")) size -= 1;
     if (!strcmp(k, "lpc") && !o->fea_c0) size--;
     if (!strcmp(k, "dctc") && !o->fea_c0) size--;
@@ -775,6 +800,9 @@ static int design_all(ctuo_t *c) {
     else kind = 9;
     if (o->fea_c0) kind |= 020000;
     if (o->fea_E) kind |= 000100;
+    if (o->fea_delta && o->n_order >= 1) kind |= 000400; /* out.cc:157-159; -fea_trap sets fea_delta and n_order=1 too */
+    if (o->fea_delta && o->n_order >= 2) kind |= 001000;
+    if (o->fea_delta && o->n_order == 3) kind |= 0100000;
     c->htk_kind = kind;
     if (c->do_vad) {
         if (!strcmp(o->vad_cri_mode, "cepdist") && !strcmp(o->vad_cepdist_mode, "lpc") && !o->phase_needed) {
@@ -981,14 +1009,123 @@ static void emit_row(const ctuo_t *c, const double *X, double E, float *row) {
     if (!strcmp(k, "spec") || !strcmp(k, "logspec") || !strcmp(k, "trapdct")) {
         for (int i = 0; i < Xsize; i++) row[i] = (float)X[i];
         if (o->fea_E) row[Xsize] = (float)E;
-    } else { /* n_order == 0 on this path */
+    } else if (c->post_stack) { /* out.cc:182: -fea_trap switches the writers to the straight "spec" copy */
+        Xsize = c->Xsize;
+        for (int i = 0; i < Xsize; i++) row[i] = (float)X[i];
+        if (o->fea_E) row[Xsize] = (float)E;
+    } else { /* out.cc:188-201: block j = (c1..cN, c0) of the j-th derivative; E once, after the last block */
         int nc = o->fea_ncepcoefs;
-        for (int i = 1; i < nc + 1; i++) row[i - 1] = (float)X[i];
-        if (o->fea_c0) {
-            row[nc] = (float)X[0];
-            if (o->fea_E) row[Xsize] = (float)E;
-        } else if (o->fea_E) row[nc] = (float)E;
+        Xsize = c->Xsize;
+        for (int j = 0; j <= c->post_order; j++) {
+            for (int i = (nc + 1) * j + 1; i < (nc + 1) * (j + 1); i++) row[i - 1] = (float)X[i];
+            if (o->fea_c0) {
+                row[nc * (j + 1) + j] = (float)X[(nc + 1) * j];
+                if (o->fea_E) row[Xsize] = (float)E;
+            } else if (o->fea_E) row[nc * (j + 1) + j] = (float)E;
+        }
     }
+}
+
+/* ------------------------------------------------------------------ deltaFEA (src/fea/fea_delta.cc)
+ * One stage of the chain BATCH::init_delta builds (batch.cc:122-125).  The reference runs it as a streaming
+ * ring of 2w+1 input vectors; the ring, its priming (first frame w times, second frame twice) and the flush
+ * (last input repeated) are kept as they are so that every edge effect of the original falls out of the same
+ * bookkeeping instead of being described by hand. */
+typedef struct {
+    int w, L;            /* delta_w, dwlen */
+    int start, end, frame, endframe, avail, index, num_c, den;
+    int n_order, nfea, fea_c, stack;
+    const double *in;    /* upstream vector (nfea values are consumed) */
+    double *out;         /* fea_c * n_order values */
+    double *ring;        /* L x nfea */
+} dstage_t;
+
+static void dstage_new_file(dstage_t *s) { /* fea_delta.cc:62-72 */
+    s->start = 0; s->end = 0; s->endframe = 1; s->frame = 1;
+    s->avail = s->w + 1; s->index = s->avail - 1; s->num_c = 1;
+}
+
+static void dstage_init(dstage_t *s, const opts_t *o, const double *in, int n_order, int w) { /* fea_delta.cc:20-60 */
+    memset(s, 0, sizeof *s);
+    s->in = in; s->fea_c = o->fea_ncepcoefs + 1;
+    s->w = w; s->L = 2 * w + 1; s->n_order = n_order; s->stack = o->fea_trap;
+    s->nfea = s->fea_c * (n_order - 1);
+    if (o->fea_trap) s->n_order = s->L;
+    s->out = calloc((size_t)s->fea_c * s->n_order, sizeof(double));
+    s->ring = calloc((size_t)s->L * s->nfea, sizeof(double));
+    for (int i = 1; i <= w; i++) s->den += i * i;
+    s->den *= 2;
+    dstage_new_file(s);
+}
+
+static void dstage_free(dstage_t *s) { free(s->out); free(s->ring); }
+
+static void dstage_prime(dstage_t *s) { /* init_cbuffer, fea_delta.cc:132-144 */
+    for (int r = 0; r < s->num_c; r++) {
+        memcpy(s->ring + (size_t)s->index * s->nfea, s->in, sizeof(double) * s->nfea);
+        s->index = (s->index + 1) % s->L;
+    }
+}
+
+static void dstage_compute(dstage_t *s) {
+    const int L = s->L, w = s->w, nf = s->nfea, fc = s->fea_c;
+    if (s->stack) { /* trap(), fea_delta.cc:166-176: coefficient-major stack of the ring in time order */
+        for (int i = 0; i < fc; i++)
+            for (int j = 0; j < L; j++) s->out[i * L + j] = s->ring[(size_t)((s->start + j) % L) * nf + i];
+        return;
+    }
+    /* delta(), fea_delta.cc:146-164: regression over the newest block of the input vector */
+    for (int j = fc * (s->n_order - 2); j < fc * (s->n_order - 1); j++) {
+        double x = 0;
+        for (int i = 1; i <= w; i++)
+            x += i * (s->ring[(size_t)((s->start + w + i) % L) * nf + j] - s->ring[(size_t)((s->start + w - i) % L) * nf + j]);
+        s->out[j + fc] = x / s->den;
+    }
+}
+
+static int dstage_process(dstage_t *s) { /* fea_delta.cc:74-130 */
+    const int L = s->L, w = s->w, nf = s->nfea;
+    if (s->avail != 0) {
+        s->num_c = s->frame == 1 ? w : (s->frame == 2 ? 2 : 1);
+        dstage_prime(s);
+        s->avail--;
+        int ready = 0;
+        if (!s->avail) {
+            dstage_compute(s);
+            memcpy(s->ring + (size_t)(L - 1) * nf, s->ring + (size_t)(L - 2) * nf, sizeof(double) * nf);
+            memcpy(s->out, s->ring + (size_t)w * nf, sizeof(double) * nf);
+            ready = 1;
+        }
+        s->start = (s->start + 1) % L;
+        s->frame++;
+        return ready;
+    }
+    int fx = s->start == 0 ? L - 1 : s->start - 1;
+    memcpy(s->ring + (size_t)fx * nf, s->in, sizeof(double) * nf);
+    dstage_compute(s);
+    int ox = fx - w;
+    if (ox < 0) ox += L;
+    if (!s->stack) memcpy(s->out, s->ring + (size_t)ox * nf, sizeof(double) * nf);
+    s->end = s->start;
+    s->start = (s->start + 1) % L;
+    s->frame++;
+    return 1;
+}
+
+static int dstage_flush(dstage_t *s) { /* fea_delta.cc:178-206 */
+    const int L = s->L, w = s->w, nf = s->nfea;
+    if (s->endframe) { s->index = s->end; s->endframe = 0; }
+    if (s->avail < w) {
+        dstage_prime(s);
+        dstage_compute(s);
+        int ox = s->start - w - 1;
+        if (ox < 0) ox += L;
+        memcpy(s->out, s->ring + (size_t)ox * nf, sizeof(double) * nf);
+        s->start = (s->start + 1) % L;
+        s->avail++;
+        return 1;
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------ the chain */
@@ -1004,6 +1141,16 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         set_err(c, "oracle: trapdct on fewer than (traplen+1)/2 frames reads never-written ring rows in the reference (src/fea/fea_trap.cc:64-70,111-127); undefined");
         return -1;
     }
+    const int is_post = c->post_order > 0;
+    if (is_post && T > 0) {
+        int wmax = o->d_win;
+        if (c->post_order >= 2 && o->a_win > wmax) wmax = o->a_win;
+        if (c->post_order >= 3 && o->t_win > wmax) wmax = o->t_win;
+        if (T < wmax + 1) {
+            set_err(c, "oracle: delta / stacking on fewer than window+1 frames emits rows built from never-written ring slots in the reference (src/fea/fea_delta.cc:74-130,178-206); undefined");
+            return -1;
+        }
+    }
     /* the circular buffer of in.cc is kept here as a linear double copy of the signal;
      * remove_dc1 mutates it persistently exactly as cbuffer is mutated (in.cc:343-350). */
     double *x = malloc(sizeof(double) * (nsamples > 0 ? nsamples : 1));
@@ -1016,6 +1163,11 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     double *fvec = calloc(c->nfea > B ? c->nfea : B, sizeof(double));
     double *Navg = malloc(sizeof(double) * K), *Yavg = malloc(sizeof(double) * K);
     double *trapbuf = NULL, *trapE = NULL, *tin = NULL;
+    double *postbuf = NULL, *postE = NULL;
+    if (is_post) {
+        postbuf = malloc(sizeof(double) * (size_t)(T > 0 ? T : 1) * c->nfea);
+        postE = malloc(sizeof(double) * (size_t)(T > 0 ? T : 1));
+    }
     if (is_trap) {
         trapbuf = malloc(sizeof(double) * (size_t)(T > 0 ? T : 1) * B);
         trapE = malloc(sizeof(double) * (size_t)(T > 0 ? T : 1));
@@ -1205,6 +1357,12 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
             continue;
         }
 
+        if (is_post) { /* deltaFEA chain replayed after the loop (it only consumes fvec and E) */
+            memcpy(postbuf + (size_t)t * c->nfea, fvec, sizeof(double) * c->nfea);
+            postE[t] = E_out;
+            continue;
+        }
+
         E_last = E_out;
         /* ---- BATCH::save_frame, batch.cc:230-241 */
         if (!do_vad) {
@@ -1292,6 +1450,47 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         }
     }
 
+    if (!fail && is_post && T > 0) {
+        /* BATCH::fea_delta (batch.cc:172-192) per frame, then BATCH::flush_fea (batch.cc:251-291).  The writers read
+         * E through a pointer, so a row carries the energy of the newest frame fed in, not of the frame it describes. */
+        const int n = c->post_order;
+        dstage_t st[3];
+        double *in0 = calloc(c->nfea, sizeof(double));
+        dstage_init(&st[0], o, in0, 2, o->d_win);
+        if (n >= 2) dstage_init(&st[1], o, st[0].out, 3, o->a_win);
+        if (n >= 3) dstage_init(&st[2], o, st[1].out, 4, o->t_win);
+        const double *X = st[n - 1].out;
+        double E_cur = -1.;
+#define POST_EMIT() do { emit_row(c, X, E_cur, rows + (size_t)nrows * c->D); nrows++; } while (0)
+        for (long t = 0; t < T; t++) {
+            memcpy(in0, postbuf + (size_t)t * c->nfea, sizeof(double) * c->nfea);
+            E_cur = postE[t];
+            if (!dstage_process(&st[0])) continue;
+            if (n >= 2) {
+                if (!dstage_process(&st[1])) continue;
+                if (n >= 3 && !dstage_process(&st[2])) continue;
+            }
+            POST_EMIT();
+        }
+        while (dstage_flush(&st[0])) {
+            if (n >= 2) {
+                if (!dstage_process(&st[1])) continue;
+                if (n >= 3 && !dstage_process(&st[2])) continue;
+            }
+            POST_EMIT();
+        }
+        if (n >= 2)
+            while (dstage_flush(&st[1])) {
+                if (n >= 3 && !dstage_process(&st[2])) continue;
+                POST_EMIT();
+            }
+        if (n >= 3)
+            while (dstage_flush(&st[2])) POST_EMIT();
+#undef POST_EMIT
+        for (int j = 0; j < n; j++) dstage_free(&st[j]);
+        free(in0);
+    }
+
     if (!fail && do_vad && !is_trap) { /* BATCH::flush_vad, batch.cc:243-249; medianFilter::flush_frame, vad.h:156-175 */
         while (vs.hsize > 0) {
             vs.history[vs.hidx] = 0;
@@ -1314,7 +1513,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     if (is_trap && do_vad && !fail) { set_err(c, "oracle: trapdct together with VAD is not restated"); fail = 1; }
 
     free(x); free(fft_in); free(Xre); free(Xim); free(zr); free(zi); free(Xabs); free(Xph); free(Y); free(fvec);
-    free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin);
+    free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin); free(postbuf); free(postE);
     free(RRe); free(rc); free(a); free(aa); free(P);
     free(vs.history); free(vs.ring); free(vs.c0); free(vs.ci); free(hw1); free(hw2); free(tsig); free(hre); free(him);
     return fail ? -1 : nrows;

@@ -170,3 +170,29 @@ def test_vad_file_and_four_column_list(tmp_path):
     # a two-column list is a format error when the VAD is on (src/io/batch.cc:356)
     r = run(C4 + ["-S", _list(tmp_path, ["CS3"], cols=2)])
     assert r.returncode == 255 and "Bad list format" in r.stderr
+
+
+@pytest.mark.gpu
+def test_delta_and_stacking_headers(tmp_path):
+    # MFCC_0_D_A: 39 floats, kind 6|_0|_D|_A (src/io/out.cc:146-159)
+    lst = _list(tmp_path, ["CS0", "CS3"])
+    cfg = C1 + ["-fea_delta", "d_a"]
+    r = run(cfg + ["-S", lst])
+    assert r.returncode == 0, r.stderr
+    orc = Oracle(cfg)
+    for name, frames in (("CS0", 594), ("CS3", 592)):
+        img = (tmp_path / (name + ".out")).read_bytes()
+        assert struct.unpack("<IIHH", img[:12]) == (frames, 100000, 156, 6 | 0o20000 | 0o400 | 0o1000)
+        got = np.frombuffer(img[12:], dtype="<f4").reshape(frames, 39)
+        assert _close(got, orc.process(sig(name)))
+    # -fea_trap: the reference's writers switch fea_kind to "spec" while saving the first frame (out.cc:182), so the
+    # first file's header says MFCC (6) and every later one says MELSPEC (8); the qualifier bits stay
+    cfg = C1 + ["-fea_trap", "5"]
+    r = run(cfg + ["-S", lst])
+    assert r.returncode == 0, r.stderr
+    orc = Oracle(cfg)
+    for name, frames, base in (("CS0", 594, 6), ("CS3", 592, 8)):
+        img = (tmp_path / (name + ".out")).read_bytes()
+        assert struct.unpack("<IIHH", img[:12]) == (frames, 100000, 65 * 4, base | 0o20000 | 0o400)
+        got = np.frombuffer(img[12:], dtype="<f4").reshape(frames, 65)
+        assert _close(got, orc.process(sig(name)))

@@ -175,3 +175,71 @@ def test_vad_drop_mode_row_counts(Engine):
 
 def test_c5_trapdct(Engine):
     _check(Engine, C5, [sig("CS3"), synth_utt(61, 30000)])
+
+
+# ---- row N1: delta chain and -fea_trap stacking (src/fea/fea_delta.cc, src/io/out.cc:188-201)
+C15 = ("-fs 16000 -format_in raw -format_out htk -w 25 -s 10 -preem 0.97 -fb_scale mel -fb_shape triang -fb_power on "
+       "-fb_definition 30filters -nr_mode none -fb_eqld off -fb_inld off -fea_kind dctc -fea_ncepcoefs 12 -fea_c0 on -fea_E off "
+       "-fea_lifter 22 -fea_rawenergy off -fea_delta d_a -d_win 2 -a_win 2 -t_win 2").split()  # egs/conf/15_*
+
+
+def _post_utts():
+    # around the 64-frame chunk of the pass and its halo: window+2 frames, 63..66, 127..130, a long one, and an empty one
+    frames = [4, 5, 9, 63, 64, 65, 66, 127, 128, 129, 130, 0, 517]
+    return [synth_utt(300 + i, 240 + 160 * f + (i % 5)) for i, f in enumerate(frames)] + [sig("CS0")]
+
+
+def test_delta_example_config_15(Engine):
+    eng = Engine(C15)
+    assert (eng.dims.row_floats, eng.dims.htk_kind) == (39, 6 | 0o20000 | 0o400 | 0o1000)
+    _check(Engine, C15, _post_utts())
+
+
+@pytest.mark.parametrize("extra", [["-fea_delta", "d"], ["-fea_delta", "d_a_t"], ["-fea_delta", "d_a", "-d_win", "1", "-a_win", "3"],
+                                   ["-fea_delta", "d_a_t", "-d_win", "3", "-a_win", "1", "-t_win", "2", "-fea_E", "on"],
+                                   ["-fea_delta", "d_a_t", "-d_win", "1", "-a_win", "1", "-t_win", "1"],
+                                   ["-fea_delta", "d_a_t", "-d_win", "8", "-a_win", "8", "-t_win", "8", "-fea_E", "on"],
+                                   ["-fea_delta", "d", "-d_win", "16"], ["-nr_mode", "exten", "-fea_delta", "d_a"]])
+def test_delta_windows_orders_energy(Engine, extra):
+    utts = [u for u in _post_utts() if (len(u) - 240) // 160 == 0 or (len(u) - 240) // 160 > 17]
+    _check(Engine, C2 + extra, utts)
+
+
+def test_delta_on_plp_cepstra(Engine):
+    _check(Engine, C3 + ["-fea_delta", "d_a"], [sig("CS0"), sig("CS3"), synth_utt(5, 30000)])
+    c4f = "-fs 8000 -preset plpc -fea_delta d_a".split()
+    x = sig("CS3")[::2].copy()
+    _check(Engine, c4f, [x, synth_utt(6, 9000)], tol=2e-4)
+
+
+@pytest.mark.parametrize("tw", [3, 5, 9, 33])
+def test_stacking(Engine, tw):
+    w = (tw - 1) // 2
+    utts = [u for u in _post_utts() if len(u) < 400 or (len(u) - 240) // 160 > w + 1]
+    for e_on in ("off", "on"):
+        _check(Engine, C2 + ["-fea_E", e_on, "-fea_trap", str(tw)], utts)
+
+
+def test_delta_blocks_are_exact_functions_of_the_base_block(Engine):
+    # size-independent property: block 0 of the wide row is bit-identical to the plain MFCC row, and the delta block
+    # is the clamped regression of block 0 evaluated in float32 (same kernel arithmetic, so a tight bound holds)
+    utts = [synth_utt(40 + i, 16000 * (3 + i)) for i in range(4)]
+    base = Engine(C2).extract(utts)
+    wide = Engine(C2 + ["-fea_delta", "d_a"]).extract(utts)
+    for b, r in zip(base, wide):
+        assert np.array_equal(r[:, :13], b)
+        T = b.shape[0]
+        idx = np.arange(T)
+        x = b.astype(np.float64)
+        for blk in (1, 2):
+            d = sum(i * (x[np.minimum(idx + i, T - 1)] - x[np.maximum(idx - i, 0)]) for i in (1, 2)) / 10.0
+            assert np.abs(r[:, 13 * blk:13 * blk + 13] - d).max() < 1e-5 * max(1.0, np.abs(d).max())
+            x = r[:, 13 * blk:13 * blk + 13].astype(np.float64)
+
+
+def test_delta_too_few_frames_is_an_input_error(Engine):
+    from ctucopy_amd import CtuError
+    eng = Engine(C2 + ["-fea_delta", "d", "-d_win", "4"])
+    with pytest.raises(CtuError, match="fewer than window"):
+        eng.extract([synth_utt(1, 240 + 160 * 5)])
+    assert eng.extract([synth_utt(1, 240 + 160 * 6)])[0].shape == (6, 26)
