@@ -1184,84 +1184,144 @@ struct PostParams {
 
 __global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ base, float *__restrict__ rows,
                                                    const int4 *__restrict__ utt_info, const int *__restrict__ chunks,
-                                                   const PostParams pp) {
+                                                   const int n_chunks, const PostParams pp) {
     extern __shared__ float psm[];
-    const int u = chunks[2 * blockIdx.x], t0 = chunks[2 * blockIdx.x + 1];
-    const int4 ui = utt_info[u];
-    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
-    const int T = ui.z;
+    constexpr int PF = 12;  // prefetch registers per thread; the host keeps R * Dbase <= 256 * PF
     const int fc = pp.fea_c, Db = pp.Dbase, D = pp.D;
     const int H = pp.stack ? pp.w[0] : pp.w[0] + (pp.order > 1 ? pp.w[1] : 0) + (pp.order > 2 ? pp.w[2] : 0);
-    const int tlo = t0 - H, R = 64 + 2 * H;
-    const int nout = min(64, T - t0);
+    const int R = 64 + 2 * H;
     float *x0 = psm;                        // [R][Db]   base rows (E column included)
     float *lv = psm + (size_t)R * Db;       // levels 1..order: [R][fc] each
-    // level 0: the contiguous run of base rows this chunk touches
-    {
-        const int flo = max(tlo, 0), fhi = min(t0 + 63 + H, T - 1);
-        const float *src = base + (ro + flo) * Db;
-        float *dst = x0 + (size_t)(flo - tlo) * Db;
+    // e / d for 0 <= e < 2^16, 1 <= d < 2^10 through the float reciprocal: (e + 0.5) / d stays at least 0.5/d away from
+    // an integer, far more than the rounding error of the product, so the truncation is exact
+    auto fdiv = [](int e, float inv) { return (int)(((float)e + 0.5f) * inv); };
+    const float invD = 1.0f / (float)D, invfc = 1.0f / (float)fc;
+    // element e = threadIdx.x + 256 q of a [frames][D] (or [frames][fc]) image: (frame, column) advance by a fixed
+    // (quotient, remainder) per step, so the loops below carry them instead of dividing
+    const int tt_first = fdiv(threadIdx.x, invD), k_first = threadIdx.x - tt_first * D;
+    const int dqD = fdiv(256, invD), drD = 256 - dqD * D;
+    const int ff_first = fdiv(threadIdx.x, invfc), cc_first = threadIdx.x - ff_first * fc;
+    const int dqF = fdiv(256, invfc), drF = 256 - dqF * fc;
+
+    struct Meta { long long ro; int T, t0; };
+    auto meta = [&](int c) {
+        const int u = chunks[2 * c];
+        const int4 ui = utt_info[u];
+        Meta m;
+        m.ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+        m.T = ui.z;
+        m.t0 = chunks[2 * c + 1];
+        return m;
+    };
+    // the contiguous run of base rows a chunk touches, into registers (the loads stay in flight while the previous
+    // chunk is being computed and written: a workgroup walks chunks blockIdx.x, +gridDim.x, ...)
+    auto issue = [&](const Meta &m, float (&r)[PF]) {
+        const int flo = max(m.t0 - H, 0), fhi = min(m.t0 + 63 + H, m.T - 1);
+        const float *src = base + (m.ro + flo) * Db;
         const int n = (fhi - flo + 1) * Db;
-        for (int e = threadIdx.x; e < n; e += 256) dst[e] = src[e];
-    }
-    __syncthreads();
-    auto rowof = [&](int f) { return min(max(f, 0), T - 1) - tlo; };
-    if (pp.stack) {
-        const int w = pp.w[0], L = 2 * w + 1, xs = fc * L;
-        for (int e = threadIdx.x; e < nout * D; e += 256) {
-            const int tt = e / D, k = e - tt * D, t = t0 + tt;
-            float v;
-            if (k == xs) v = x0[(size_t)rowof(t + w) * Db + fc];  // E
-            else {
-                int i, f;
-                if (k < fc && (t == 0 || t >= T - w)) { i = k; f = t; }
-                else {
-                    i = k / L;
-                    const int j = k - i * L;
-                    if (t == 0) f = j < w ? 0 : max(1, j - w);
-                    else if (w == 1 && t == T - 1) f = T - 1;
-                    else f = t - w + j;
-                }
-                v = x0[(size_t)rowof(f) * Db + (i == 0 ? fc - 1 : i - 1)];
-            }
-            rows[(ro + t0) * D + e] = v;
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int e = threadIdx.x + 256 * q;
+            r[q] = e < n ? src[e] : 0.f;
         }
-        return;
-    }
-    int hk = H;
-    const float *prev = x0;
-    int pstride = Db;
-    for (int k = 0; k < pp.order; k++) {
-        const int w = pp.w[k];
-        hk -= w;  // halo this level still needs for the stages after it
-        float *cur = lv + (size_t)k * R * fc;
-        const int flo = max(t0 - hk, 0), fhi = min(t0 + 63 + hk, T - 1);
-        const int n = (fhi - flo + 1) * fc;
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const int ff = e / fc, c = e - ff * fc, f = flo + ff;
-            float acc = 0.f;
-            for (int i = 1; i <= w; i++) acc += (float)i * (prev[(size_t)rowof(f + i) * pstride + c] - prev[(size_t)rowof(f - i) * pstride + c]);
-            acc *= pp.inv_den[k];
-            if (w == 1 && f == T - 1) acc = 0.f;
-            cur[(size_t)(f - tlo) * fc + c] = acc;
+    };
+
+    int c = blockIdx.x;
+    if (c >= n_chunks) return;
+    Meta m = meta(c);
+    float r[PF];
+    issue(m, r);
+    while (true) {
+        const int t0 = m.t0, T = m.T, tlo = t0 - H;
+        const long long ro = m.ro;
+        const int nout = min(64, T - t0);
+        {
+            const int flo = max(tlo, 0), fhi = min(t0 + 63 + H, T - 1);
+            float *dst = x0 + (size_t)(flo - tlo) * Db;
+            const int n = (fhi - flo + 1) * Db;
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int e = threadIdx.x + 256 * q;
+                if (e < n) dst[e] = r[q];
+            }
         }
         __syncthreads();
-        prev = cur;
-        pstride = fc;
-    }
-    const int xs = fc * (pp.order + 1);
-    for (int e = threadIdx.x; e < nout * D; e += 256) {
-        const int tt = e / D, k = e - tt * D, t = t0 + tt;
-        float v;
-        if (k == xs) v = x0[(size_t)rowof(t + H) * Db + fc];  // E
-        else {
-            const int j = k / fc, c = k - j * fc;
-            v = j == 0 ? x0[(size_t)(t - tlo) * Db + c] : lv[((size_t)(j - 1) * R + (t - tlo)) * fc + c];
+        const int cn = c + gridDim.x;
+        const bool more = cn < n_chunks;
+        Meta mn = m;
+        if (more) {
+            mn = meta(cn);
+            issue(mn, r);
         }
-        rows[(ro + t0) * D + e] = v;
+        auto rowof = [&](int f) { return min(max(f, 0), T - 1) - tlo; };
+        if (pp.stack) {
+            const int w = pp.w[0], L = 2 * w + 1, xs = fc * L;
+            const float invL = 1.0f / (float)L;
+            int tt = tt_first, k = k_first;
+            for (int e = threadIdx.x; e < nout * D; e += 256, tt += dqD, k += drD) {
+                if (k >= D) { k -= D; tt++; }
+                const int t = t0 + tt;
+                float v;
+                if (k == xs) v = x0[(size_t)rowof(t + w) * Db + fc];  // E
+                else {
+                    int i, f;
+                    if (k < fc && (t == 0 || t >= T - w)) { i = k; f = t; }
+                    else {
+                        i = fdiv(k, invL);
+                        const int j = k - i * L;
+                        if (t == 0) f = j < w ? 0 : max(1, j - w);
+                        else if (w == 1 && t == T - 1) f = T - 1;
+                        else f = t - w + j;
+                    }
+                    v = x0[(size_t)rowof(f) * Db + (i == 0 ? fc - 1 : i - 1)];
+                }
+                rows[(ro + t0) * D + e] = v;
+            }
+        } else {
+            int hk = H;
+            const float *prev = x0;
+            int pstride = Db;
+            for (int k = 0; k < pp.order; k++) {
+                const int w = pp.w[k];
+                hk -= w;  // halo this level still needs for the stages after it
+                float *cur = lv + (size_t)k * R * fc;
+                const int flo = max(t0 - hk, 0), fhi = min(t0 + 63 + hk, T - 1);
+                const int n = (fhi - flo + 1) * fc;
+                int ff = ff_first, cc = cc_first;
+                for (int e = threadIdx.x; e < n; e += 256, ff += dqF, cc += drF) {
+                    if (cc >= fc) { cc -= fc; ff++; }
+                    const int f = flo + ff;
+                    float acc = 0.f;
+                    for (int i = 1; i <= w; i++)
+                        acc += (float)i * (prev[(size_t)rowof(f + i) * pstride + cc] - prev[(size_t)rowof(f - i) * pstride + cc]);
+                    acc *= pp.inv_den[k];
+                    if (w == 1 && f == T - 1) acc = 0.f;
+                    cur[(size_t)(f - tlo) * fc + cc] = acc;
+                }
+                __syncthreads();
+                prev = cur;
+                pstride = fc;
+            }
+            const int xs = fc * (pp.order + 1);
+            int tt = tt_first, k = k_first;
+            for (int e = threadIdx.x; e < nout * D; e += 256, tt += dqD, k += drD) {
+                if (k >= D) { k -= D; tt++; }
+                const int t = t0 + tt;
+                float v;
+                if (k == xs) v = x0[(size_t)rowof(t + H) * Db + fc];  // E
+                else {
+                    const int j = (k >= fc) + (k >= 2 * fc) + (k >= 3 * fc), cc = k - j * fc;
+                    v = j == 0 ? x0[(size_t)(t - tlo) * Db + cc] : lv[((size_t)(j - 1) * R + (t - tlo)) * fc + cc];
+                }
+                rows[(ro + t0) * D + e] = v;
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // every read of this chunk's LDS image is done before the next one is written
+        c = cn;
+        m = mn;
     }
 }
-
 
 struct ctu_engine {
     std::unique_ptr<ctu::Design> design;
@@ -2035,8 +2095,10 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             }
             const int R = 64 + 2 * H;
             const size_t shm = ((size_t)R * d.Dbase + (size_t)(d.post_stack ? 0 : d.post_order) * R * pp.fea_c) * sizeof(float);
-            hipLaunchKernelGGL(post_kernel, dim3(pl->n_trap_chunks), dim3(256), shm, s, e->base_rows.p, d_rows,
-                               pl->utt_info.p, pl->trap_chunks.p, pp);
+            if ((size_t)R * d.Dbase > 256 * 12) throw std::runtime_error("delta tile larger than the prefetch registers");
+            const int pgrid = std::min(pl->n_trap_chunks, e->n_cu * 8);
+            hipLaunchKernelGGL(post_kernel, dim3(pgrid), dim3(256), shm, s, e->base_rows.p, d_rows,
+                               pl->utt_info.p, pl->trap_chunks.p, pl->n_trap_chunks, pp);
             HIP_TRY(hipGetLastError());
         }
     } catch (const std::exception &ex) {
