@@ -58,8 +58,6 @@ constexpr int LTW_STRIDE = 116, LTW_FLOATS = 16 * LTW_STRIDE;
 // band_log, band_to_scratch); LP covers lpc and lpa (runtime flag lp_is_lpa).
 enum FeatMode { FEAT_BANDS = 0, FEAT_DCTC = 2, FEAT_LP = 3 };
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 struct KParams {
     const int16_t *pcm;
     float *rows;
@@ -83,12 +81,7 @@ struct KParams {
     float preem, inv_window;
     int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
     float nr_p, nr_a;
-    // matrix-core phase 2 (MM instantiations): filter bank as the A operand of v_mfma_f32_16x16x4_f32, one 64-float
-    // record per (16-band tile, 4-bin step) in lane order; the DCT B operands sit in the LDS table area
-    const float *mm_fb;
-    int mm_nt, mm_step0[4], mm_n[4], mm_kb[4];
     unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
-    int dbg2;  // MM experiments: 1 = A operand constant, 2 = A operand from an LDS stand-in
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
 
@@ -238,8 +231,7 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
 // MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
 //         (no twiddles in the untangle), NZ = rows of 16 samples, one pass of 8 frames.
 // VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
-// MM:     phase 2 on the matrix cores (filter bank and DCT as 16x16x4 fp32 MFMAs); FEAT_BANDS / FEAT_DCTC only.
-template <int NZ, int FEAT, int MODE, bool VX, bool MM>
+template <int NZ, int FEAT, int MODE, bool VX>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
@@ -634,105 +626,6 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     esum += ((k == 0 || k == p.K - 1) ? 0.5f : 1.0f) * x * x;
                 }
             }
-            if constexpr (MM) {
-                // ---- filter bank: Y^T[band][frame] = FB[band][bin] * P^T[bin][frame] per 16-band tile, K = 4 bins per
-                // MFMA.  A (weights) streams from global memory in lane order (one coalesced 256-byte load per step,
-                // L1-resident: the whole table is a few KB); B is this wave's P rows: lane (k = lane>>4, n = lane&15)
-                // reads P[frame n & 7][bin0 + k] - bank (4 n + k) mod 64, conflict-free with PSTRIDE = 260.  Frame
-                // columns 8..15 repeat 0..7 (a wave owns 8 frames); their results are never stored.
-                const int q = lane >> 4, col = lane & 15, fr = lane & 7;
-                const float *pb = Pt + (wave * 8 + fr) * PSTRIDE + q;
-                f32x4 yb[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    yb[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (t < p.mm_nt) {
-                        const float *ap = p.mm_fb + (size_t)p.mm_step0[t] * 64 + lane;
-                        const float *apl = Pt + lane;  // stand-in
-                        const int astride = p.dbg2 == 1 ? 0 : 64;
-                        const float *bp = pb + p.mm_kb[t];
-                        const int n = p.mm_n[t];  // multiple of 4 (zero-weight steps pad the run)
-                        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-                        float an[4];
-#pragma unroll
-                        for (int u_ = 0; u_ < 4; u_++) an[u_] = ap[u_ * 64];
-                        for (int s_ = 0; s_ < n; s_ += 4) {
-                            float ac[4], bv[4];
-#pragma unroll
-                            for (int u_ = 0; u_ < 4; u_++) ac[u_] = an[u_];
-                            if (p.dbg2 == 2) {
-#pragma unroll
-                                for (int u_ = 0; u_ < 4; u_++) an[u_] = apl[(s_ + 4 + u_) * 64];
-                            } else if (p.dbg2 == 1) {
-                            } else
-                            if (s_ + 4 < n) {
-#pragma unroll
-                                for (int u_ = 0; u_ < 4; u_++) an[u_] = ap[(s_ + 4 + u_) * astride];
-                            }
-#pragma unroll
-                            for (int u_ = 0; u_ < 4; u_++) bv[u_] = bp[4 * (s_ + u_)];
-                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0], bv[0], a0, 0, 0, 0);
-                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1], bv[1], a1, 0, 0, 0);
-                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[2], bv[2], a0, 0, 0, 0);
-                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[3], bv[3], a1, 0, 0, 0);
-                        }
-                        yb[t] = a0 + a1;
-                    }
-                }
-                // this lane now holds bands 16 t + 4 q + r (r = 0..3) of frame column `col`
-                float esum3 = 0.f;
-                const bool colvalid = col < nv;  // col < 8 implied
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if (t < p.mm_nt) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int band = 16 * t + 4 * q + r;
-                            float y = yb[t][r];
-                            if (p.e_mode == 3 && band < p.B) esum3 += ((band == 0 || band == p.B - 1) ? 0.5f : 1.0f) * y * y;
-                            if (p.fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));
-                            if (FEAT == FEAT_DCTC || p.band_log) y = __builtin_amdgcn_logf(y) * 0.69314718056f;
-                            if (FEAT == FEAT_BANDS) {
-                                float *dst = p.band_to_scratch ? p.logmel : p.rows;
-                                const int out_w = p.band_to_scratch ? p.B : p.D;
-                                if (band < p.B && colvalid) dst[(rbase + wave * 8 + col) * out_w + band] = y;
-                            } else {
-                                yb[t][r] = band < p.B ? y : 0.f;  // idle rows: log(0) must not meet the zero coefficients
-                            }
-                        }
-                    }
-                }
-                if (p.e_mode == 3 && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
-                    esum3 += __shfl_xor(esum3, 16);
-                    esum3 += __shfl_xor(esum3, 32);
-                    if (q == 0 && colvalid) p.rows[(rbase + wave * 8 + col) * p.D + p.e_slot] = __logf(2.0f * esum3);
-                }
-                if constexpr (FEAT == FEAT_DCTC) {
-                    // ---- DCT: C[frame][slot] = logY[frame][band] * DCT[band][slot].  The log-mel registers already
-                    // are a valid A operand (i = frame column, k = q) if the contraction runs over bands in the order
-                    // (r, q); the B records in LDS are laid out for exactly that order.
-                    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        if (t < p.mm_nt) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[t][r], ltab[(t * 4 + r) * 64 + lane], o, 0, 0, 0);
-                        }
-                    }
-                    // o[r] = output slot `col` of frame 4 q + r; frames 0..7 live in q = 0, 1
-                    if (q < 2 && col < p.ncoef_out) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            if (4 * q + r < nv) p.rows[(rbase + wave * 8 + 4 * q + r) * p.D + col] = o[r];
-                    }
-                }
-                STAMP(8);
-                if (p.e_mode == 1 || p.e_mode == 4) {
-                    const float e = __logf((p.e_mode == 1 ? 2.0f : 1.0f) * lanes8_allreduce_add(esum));
-                    if (fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
-                }
-                STAMP(10);
-            } else {
             for (int sl = 0; sl < p.NS; sl++) {
                 const int cb = slot_chunk[sl], ce = slot_chunk[sl + 1];
                 // {first bin of the cell's chunk run, band index or -1}: the only per-lane indirection of the slot
@@ -873,7 +766,6 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             STAMP(10);  // reduction, tail, row store
-            }  // !MM
         }
         if (p.nr_exten) __syncthreads();  // the bin-wise NR pass of the next tile reads every wave's rows
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1168,6 +1060,8 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
 // read straight from an LDS tile of log-mel frames.  Rows of G sum to zero, so each column is offset by its centre
 // value first (keeps the fp32 accumulation small).
 // One workgroup = 64 output frames of one utterance (4 waves x 16 frames), all bands.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int NRB, int NSM>  // row blocks of 16 DCT coefficients (ndct <= 16*NRB); NSM >= ceil(traplen/4) tap groups
 __global__ __launch_bounds__(256) void trapdct_mfma_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
                                                            const float *__restrict__ G, const int4 *__restrict__ utt_info,
@@ -1437,9 +1331,7 @@ struct ctu_engine {
     int feat = FEAT_DCTC;
     int nz = 16;
     int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
-    DevBuf<float> lanec, ftab, trapG, mmfb;
-    bool mm = false;  // phase 2 on the matrix cores
-    int mm_nt = 0, mm_step0[4] = {0, 0, 0, 0}, mm_n[4] = {0, 0, 0, 0}, mm_kb[4] = {0, 0, 0, 0};
+    DevBuf<float> lanec, ftab, trapG;
     DevBuf<int> itab;
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     size_t lds_bytes = 0;
@@ -1701,93 +1593,6 @@ double check_phase2(const ctu::Design &d, const Phase2Tables &t) {
     return worst;
 }
 
-// Tables of the matrix-core phase 2.  fb: one 64-float record per (tile, step) - lane l holds the weight of band
-// 16 tile + (l & 15) at bin kb[tile] + 4 step + (l >> 4).  dct: record (tile, r) - lane l holds the coefficient that
-// output slot (l & 15) applies to band 16 tile + 4 (l >> 4) + r.
-struct MMTables {
-    std::vector<float> fb, dct;
-    int nt = 0, step0[4] = {0, 0, 0, 0}, n[4] = {0, 0, 0, 0}, kb[4] = {0, 0, 0, 0};
-};
-
-bool mm_eligible(const ctu::Design &d) {
-    if (const char *v = getenv("CTU_PHASE2"))
-        if (std::string(v) == "valu") return false;
-    if (d.B > 64) return false;
-    if (d.kind == ctu::FeaKind::Dctc) return d.nfea <= 16;
-    return d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec || d.kind == ctu::FeaKind::TrapDct;
-}
-
-void build_mm(const ctu::Design &d, MMTables &t) {
-    const int B = d.B;
-    t.nt = (B + 15) / 16;
-    for (int ti = 0; ti < t.nt; ti++) {
-        int lo = PSTRIDE, hi = 0;
-        for (int b = 16 * ti; b < std::min(B, 16 * ti + 16); b++) {
-            lo = std::min(lo, d.fb_first[b]);
-            hi = std::max(hi, d.fb_last[b]);
-        }
-        if (hi < lo) { lo = 0; hi = 0; }
-        int kb = lo & ~3;
-        int n = ((hi - kb) / 4 + 1 + 3) & ~3;          // steps, padded to a multiple of 4
-        if (4 * n > PSTRIDE) throw std::runtime_error("filter bank tile wider than the spectrum row");
-        kb = std::min(kb, PSTRIDE - 4 * n);             // the padded run stays inside the row (extra bins get weight 0)
-        t.step0[ti] = (int)t.fb.size() / 64;
-        t.n[ti] = n;
-        t.kb[ti] = kb;
-        for (int s_ = 0; s_ < n; s_++)
-            for (int l = 0; l < 64; l++) {
-                const int b = 16 * ti + (l & 15), k = kb + 4 * s_ + (l >> 4);
-                float w = 0.f;
-                if (b < B && k < d.K && k >= d.fb_first[b] && k <= d.fb_last[b]) w = (float)d.fb[b][k];
-                t.fb.push_back(w);
-            }
-    }
-    if (d.kind == ctu::FeaKind::Dctc) {
-        std::vector<int> coef_of_slot(16, -1);
-        for (int i = 0; i < d.nfea; i++)
-            if (d.row_slot[i] >= 0) coef_of_slot[d.row_slot[i]] = i;
-        for (int ti = 0; ti < t.nt; ti++)
-            for (int r = 0; r < 4; r++)
-                for (int l = 0; l < 64; l++) {
-                    const int b = 16 * ti + 4 * (l >> 4) + r, slot = l & 15;
-                    float w = 0.f;
-                    if (b < B && coef_of_slot[slot] >= 0) w = (float)d.dct[(size_t)coef_of_slot[slot] * B + b];
-                    t.dct.push_back(w);
-                }
-    }
-}
-
-// Dense filter bank (and DCT) rebuilt from the records; largest deviation from the float-rounded design (0 = consistent).
-double check_mm(const ctu::Design &d, const MMTables &t) {
-    double worst = 0;
-    std::vector<std::vector<double>> fb(d.B, std::vector<double>(PSTRIDE, 0.0));
-    for (int ti = 0; ti < t.nt; ti++)
-        for (int s_ = 0; s_ < t.n[ti]; s_++)
-            for (int l = 0; l < 64; l++) {
-                const int b = 16 * ti + (l & 15), k = t.kb[ti] + 4 * s_ + (l >> 4);
-                const float w = t.fb[(size_t)(t.step0[ti] + s_) * 64 + l];
-                if (k < 0 || k >= PSTRIDE) return 1e30;
-                if (b >= d.B) { if (w != 0.f) return 1e30; continue; }
-                fb[b][k] += w;
-            }
-    for (int b = 0; b < d.B; b++)
-        for (int k = 0; k < PSTRIDE; k++) {
-            const double want = (k < d.K && k >= d.fb_first[b] && k <= d.fb_last[b]) ? (double)(float)d.fb[b][k] : 0.0;
-            worst = std::max(worst, std::fabs(fb[b][k] - want));
-        }
-    if (d.kind == ctu::FeaKind::Dctc)
-        for (int i = 0; i < d.nfea; i++) {
-            const int slot = d.row_slot[i];
-            if (slot < 0) continue;
-            for (int b = 0; b < d.B; b++) {
-                const int ti = b / 16, qq = (b % 16) / 4, r = b % 4;
-                const float w = t.dct[(size_t)(ti * 4 + r) * 64 + qq * 16 + slot];
-                worst = std::max(worst, std::fabs((double)w - (double)(float)d.dct[(size_t)i * d.B + b]));
-            }
-        }
-    return worst;
-}
-
 void build_tables(ctu_engine *e) {
     const ctu::Design &d = *e->design;
     const double pi = 3.14159265358979323846;
@@ -1826,22 +1631,6 @@ void build_tables(ctu_engine *e) {
     e->NS = t.NS;
     e->CW = t.CW;
     e->lift_off = t.lift_off;
-    e->mm = mm_eligible(d);
-    if (e->mm) {
-        MMTables m;
-        build_mm(d, m);
-        if (check_mm(d, m) != 0.0) throw std::runtime_error("internal: matrix-core phase-2 tables do not reproduce the filter bank / DCT");
-        e->mm_nt = m.nt;
-        for (int i = 0; i < 4; i++) { e->mm_step0[i] = m.step0[i]; e->mm_n[i] = m.n[i]; e->mm_kb[i] = m.kb[i]; }
-        e->mmfb.upload(m.fb);
-        // LDS table area = the DCT records only; the lifter (LP tail) keeps its place behind the image
-        std::vector<float> ft(m.dct);
-        e->tab_floats = (int)ft.size();
-        e->lift_off = (int)ft.size();
-        for (double v : d.lifter) ft.push_back((float)v);
-        ft.push_back(0.f);
-        t.ft = ft;
-    }
     e->ftab.upload(t.ft);
     e->itab.upload(t.it);
     e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS) * sizeof(float);
@@ -1862,29 +1651,30 @@ void build_tables(ctu_engine *e) {
 }
 
 template <int NZ, int MODE, bool VX>
-void launch_nz(int feat, bool mm, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
-#define LAUNCH(F, M)                                                                                   \
-    {                                                                                                  \
+void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
+#define LAUNCH(F)                                                                                      \
+    case F: {                                                                                          \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX, M>), \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX, M>), grid, dim3(WG), shm, s, kp);          \
+        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX>), grid, dim3(WG), shm, s, kp);             \
+        break;                                                                                         \
     }
-    if (feat == FEAT_LP) LAUNCH(FEAT_LP, false)
-    else if (feat == FEAT_DCTC && mm) LAUNCH(FEAT_DCTC, true)
-    else if (feat == FEAT_DCTC) LAUNCH(FEAT_DCTC, false)
-    else if (mm) LAUNCH(FEAT_BANDS, true)
-    else LAUNCH(FEAT_BANDS, false)
+    switch (feat) {
+        LAUNCH(FEAT_BANDS)
+        LAUNCH(FEAT_DCTC)
+        LAUNCH(FEAT_LP)
+    }
 #undef LAUNCH
 }
 
 template <int NZ, int MODE>
-void launch_vx(bool vx, int feat, bool mm, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
-    if (vx) launch_nz<NZ, MODE, true>(feat, mm, grid, s, kp, shm);
-    else launch_nz<NZ, MODE, false>(feat, mm, grid, s, kp, shm);
+void launch_vx(bool vx, int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
+    if (vx) launch_nz<NZ, MODE, true>(feat, grid, s, kp, shm);
+    else launch_nz<NZ, MODE, false>(feat, grid, s, kp, shm);
 }
 
 std::vector<std::string> to_args(int argc, const char *const *argv) {
@@ -1944,14 +1734,6 @@ int64_t ctu_config_table(int argc, const char *const *argv, const char *name, do
             Phase2Tables t;
             build_phase2(d, t);
             v = {check_phase2(d, t), (double)t.slot_chunk.back(), (double)t.NS};
-        }
-        else if (n == "mm_check") {
-            if (!mm_eligible(d)) v = {-1.0, 0.0, 0.0};
-            else {
-                MMTables t;
-                build_mm(d, t);
-                v = {check_mm(d, t), (double)(t.fb.size() / 64), (double)t.nt};
-            }
         }
         else {
             g_create_error = "unknown table name";
@@ -2237,10 +2019,6 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.nr_exten = d.o.nr_mode == "exten";
         kp.nr_p = (float)d.o.nr_p;
         kp.nr_a = (float)d.o.nr_a;
-        kp.mm_fb = e->mmfb.p;
-        kp.mm_nt = e->mm_nt;
-        for (int i = 0; i < 4; i++) { kp.mm_step0[i] = e->mm_step0[i]; kp.mm_n[i] = e->mm_n[i]; kp.mm_kb[i] = e->mm_kb[i]; }
-        kp.dbg2 = getenv("CTU_DEBUG2") ? atoi(getenv("CTU_DEBUG2")) : 0;
         kp.dbg = getenv("CTU_DEBUG_MODE") ? atoi(getenv("CTU_DEBUG_MODE")) : 0;
         const int grid = pl->grid;
 #if CTU_STAMP
@@ -2250,8 +2028,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #endif
         HIP_TRY(hipEventRecord(e->ev0, s));
         switch (e->nz) {
-            case 13: e->mode ? launch_vx<13, 1>(kp.vad_export, e->feat, e->mm, dim3(grid), s, kp, e->lds_bytes) : launch_vx<13, 0>(kp.vad_export, e->feat, e->mm, dim3(grid), s, kp, e->lds_bytes); break;
-            default: e->mode ? launch_vx<16, 1>(kp.vad_export, e->feat, e->mm, dim3(grid), s, kp, e->lds_bytes) : launch_vx<16, 0>(kp.vad_export, e->feat, e->mm, dim3(grid), s, kp, e->lds_bytes); break;
+            case 13: e->mode ? launch_vx<13, 1>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_vx<13, 0>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            default: e->mode ? launch_vx<16, 1>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_vx<16, 0>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes); break;
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
