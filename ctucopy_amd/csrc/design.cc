@@ -312,6 +312,9 @@ Design::Design(const Opts &opts) : o(opts) {
             D = xs + (o.fea_E ? 1 : 0);
         }
     }
+    if (o.fea_Z_exp > 0) cms = 1;
+    if (o.fea_Z_block > 0) cms = 2;  // block wins when both are given (src/fea/post_impl.cc:163-167)
+    if (cms) cms_cols = ncep + (o.fea_c0 ? 1 : 0);
     if (D > 32767) throw DesignError("OUT: HTK format does not support more than 32767 features!");
     period = (unsigned)std::floor(.5 + 10000000. * wshift / (double)o.fs);
     int kcode = 9;

@@ -35,6 +35,8 @@ struct Design {
     int post_order = 0;        // number of chained deltaFEA stages (0 = none; -fea_trap: 1)
     bool post_stack = false;   // -fea_trap: the single stage stacks 2*d_win+1 frames instead of differentiating
     int post_w[3] = {0, 0, 0}; // window half-width of each stage (d_win, a_win, t_win)
+    int cms = 0;               // cepstral mean subtraction after the chain: 0 off, 1 exponential, 2 block (src/fea/post_impl.cc:159-240)
+    int cms_cols = 0;          // leading row columns it touches (c1..cN and, with -fea_c0, c0)
     int htk_kind = 0;  // HTK parameter kind incl. qualifier bits
     unsigned period = 0;
 

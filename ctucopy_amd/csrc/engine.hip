@@ -1323,6 +1323,86 @@ __global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ bas
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row N2, CMS part: cms_POST (src/fea/post_impl.cc:159-240) - a running cepstral mean subtracted from the first
+// fea_ncepcoefs+1 entries of the vector that is about to be written, state reset per file (src/io/batch.cc:388-392).
+// In row terms: columns [0, ncols) of block 0.  Source = the front end's base rows (block 0 of a delta row is the
+// base row), destination = the final rows; `copy_rest` also carries the remaining base columns (E) when no delta
+// pass wrote them.  The reference keeps the mean in `float`; the arithmetic below rounds where it rounds.
+//   exp:    m = fl32(fl32(m z) + F (1 - z));  out = F - m                       (sequential in t; one lane per column)
+//   block:  t >= L-1: m = fl32(sum over ring slots x = 0..L-1 of F[newest frame == x mod L]) / L;  out = F - m
+//           t <  L-1: out = F                                                   (64-frame chunks, LDS tile with L-1 halo)
+struct CmsParams {
+    int ncols, Dbase, D, copy_rest, L;
+    float z, omz;
+};
+
+__global__ __launch_bounds__(64) void cms_exp_kernel(const float *__restrict__ base, float *__restrict__ rows,
+                                                     const int4 *__restrict__ utt_info, int n_utt, const CmsParams cp) {
+    const int u = blockIdx.x * 2 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+    if (u >= n_utt) return;
+    const int4 ui = utt_info[u];
+    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+    const int T = ui.z;
+    const float *src = base + ro * cp.Dbase;
+    float *dst = rows + ro * cp.D;
+    if (c < cp.ncols) {
+        float m = 0.f;
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) f[i] = t0 + i < T ? src[(size_t)(t0 + i) * cp.Dbase + c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (t0 + i < T) {
+                    m = __fmaf_rn(f[i], cp.omz, __fmul_rn(m, cp.z));
+                    dst[(size_t)(t0 + i) * cp.D + c] = f[i] - m;
+                }
+            }
+        }
+    } else if (cp.copy_rest && c < cp.Dbase) {
+        for (int t = 0; t < T; t++) dst[(size_t)t * cp.D + c] = src[(size_t)t * cp.Dbase + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void cms_block_kernel(const float *__restrict__ base, float *__restrict__ rows,
+                                                        const int4 *__restrict__ utt_info, const int *__restrict__ chunks,
+                                                        const CmsParams cp) {
+    extern __shared__ float csm[];  // [64 + L - 1][ncols]
+    const int u = chunks[2 * blockIdx.x], t0 = chunks[2 * blockIdx.x + 1];
+    const int4 ui = utt_info[u];
+    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+    const int T = ui.z, L = cp.L, nc = cp.ncols;
+    const int nout = min(64, T - t0);
+    const int flo = max(t0 - (L - 1), 0);
+    const int nrow = t0 + nout - flo;
+    for (int e = threadIdx.x; e < nrow * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        csm[e] = base[(ro + flo + r) * cp.Dbase + c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nout * nc; e += 256) {
+        const int tt = e / nc, c = e - tt * nc, t = t0 + tt;
+        const float f = csm[(t - flo) * nc + c];
+        float m = 0.f;
+        if (t >= L - 1) {
+            // ring slot x holds the newest frame congruent to x mod L: frame t - ((t - x) mod L)
+            const int tm = t % L;
+            for (int x = 0; x < L; x++) {
+                const int back = tm >= x ? tm - x : tm - x + L;
+                m += csm[(t - back - flo) * nc + c];
+            }
+            m = m / (float)L;
+        }
+        rows[(ro + t) * cp.D + c] = f - m;
+    }
+    if (cp.copy_rest)
+        for (int e = threadIdx.x; e < nout * (cp.Dbase - nc); e += 256) {
+            const int tt = e / (cp.Dbase - nc), c = nc + e - tt * (cp.Dbase - nc);
+            rows[(ro + t0 + tt) * cp.D + c] = base[(ro + t0 + tt) * cp.Dbase + c];
+        }
+}
+
 struct ctu_engine {
     std::unique_ptr<ctu::Design> design;
     int device = 0;
@@ -1388,7 +1468,15 @@ std::string unsupported_reason(const ctu::Design &d) {
         }
         if (wsum > 24) return "delta windows adding up to more than 24 frames (LDS tile of the chain)";
     }
-    if (o.stat_cmvn || o.apply_cmvn || o.fea_Z_exp > 0 || o.fea_Z_block > 0) return "CMVN / CMS (next row N2)";
+    if (o.stat_cmvn || o.apply_cmvn) return "per-speaker CMVN (next row N2, second part)";
+    if (d.cms) {
+        if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "CMS on non-cepstral kinds (the reference walks fea_ncepcoefs+1 entries whatever the vector holds, src/fea/post_impl.cc:203-240)";
+        if (d.post_stack) return "CMS on stacked vectors";
+        if (o.do_vad()) return "VAD together with CMS";
+        if (d.cms == 2 && (o.length_b < 1 || o.length_b > 512)) return "block CMS window outside 1..512 frames";
+        if (d.cms_cols > 32) return "more than 32 CMS columns";
+        if (d.cms == 2 && (size_t)(64 + o.length_b - 1) * d.cms_cols * sizeof(float) > 64 * 1024) return "block CMS tile above 64 KiB of LDS";
+    }
     if (o.fea_E && d.kind == ctu::FeaKind::TrapDct) return "-fea_E with trapdct (the energy lags the features by 50 frames in the reference)";
     if (o.do_vad()) {
         if (d.kind == ctu::FeaKind::TrapDct) return "VAD together with trapdct";
@@ -1939,13 +2027,13 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
                 pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
-        if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0) {
+        if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0 || d.cms) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
             pl->n_trap_chunks = (int)chunks.size() / 2;
         }
         if (d.kind == ctu::FeaKind::TrapDct && e->logmel.n < (size_t)ro * d.B) e->logmel.alloc((size_t)ro * d.B);
-        if (d.post_order > 0 && e->base_rows.n < (size_t)ro * d.Dbase) e->base_rows.alloc((size_t)ro * d.Dbase);
+        if ((d.post_order > 0 || d.cms) && e->base_rows.n < (size_t)ro * d.Dbase) e->base_rows.alloc((size_t)ro * d.Dbase);
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
@@ -1974,7 +2062,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         KParams kp;
         std::memset(&kp, 0, sizeof kp);
         kp.pcm = d_pcm;
-        kp.rows = d.post_order > 0 ? e->base_rows.p : d_rows;
+        kp.rows = (d.post_order > 0 || d.cms) ? e->base_rows.p : d_rows;
         kp.logmel = e->logmel.p;
         kp.xri = pl->xri.p;
         kp.pnr = pl->pnr.p;
@@ -2099,6 +2187,25 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const int pgrid = std::min(pl->n_trap_chunks, e->n_cu * 8);
             hipLaunchKernelGGL(post_kernel, dim3(pgrid), dim3(256), shm, s, e->base_rows.p, d_rows,
                                pl->utt_info.p, pl->trap_chunks.p, pl->n_trap_chunks, pp);
+            HIP_TRY(hipGetLastError());
+        }
+        if (d.cms) {
+            CmsParams cp;
+            std::memset(&cp, 0, sizeof cp);
+            cp.ncols = d.cms_cols;
+            cp.Dbase = d.Dbase;
+            cp.D = d.D;
+            cp.copy_rest = d.post_order > 0 ? 0 : 1;
+            cp.L = d.o.length_b;
+            cp.z = d.o.fea_Z_exp;
+            cp.omz = 1 - d.o.fea_Z_exp;
+            if (d.cms == 1)
+                hipLaunchKernelGGL(cms_exp_kernel, dim3((pl->n_utt + 1) / 2), dim3(64), 0, s, e->base_rows.p, d_rows,
+                                   pl->utt_info.p, pl->n_utt, cp);
+            else
+                hipLaunchKernelGGL(cms_block_kernel, dim3(pl->n_trap_chunks), dim3(256),
+                                   (size_t)(64 + cp.L - 1) * cp.ncols * sizeof(float), s, e->base_rows.p, d_rows,
+                                   pl->utt_info.p, pl->trap_chunks.p, cp);
             HIP_TRY(hipGetLastError());
         }
     } catch (const std::exception &ex) {

@@ -310,6 +310,8 @@ void Opts::check_config() {  // src/io/opts.cc:255-325
     for (int p = 1048576; p > 4; p /= 2)
         if (window / p == 1) wfft = p * (1 + (window % p != 0));
     wfftby2 = wfft / 2 + 1;
+    if (fea_Z_block != -1) length_b = (int)std::floor((fea_Z_block - window_ms) / wshift_ms) + 1;
+    if (fea_Z_exp != -1) fea_Z_exp = (float)1 - (2 * wshift_ms) / fea_Z_exp;
     const bool natural_little = true;  // gfx950 hosts are x86-64
     swap_in = endian_in_little != natural_little;
     swap_out = endian_out_little != natural_little;

@@ -41,7 +41,8 @@ struct Opts {
     bool fea_c0 = true, fea_E = false, fea_rawenergy = false;
     int fea_lifter = 22;
     int fea_trapdct_traplen = 0, fea_trapdct_ndct = 0;
-    float fea_Z_exp = -1, fea_Z_block = -1;
+    float fea_Z_exp = -1, fea_Z_block = -1;  // after check_config fea_Z_exp holds the forgetting factor (src/io/opts.cc:273-274)
+    int length_b = 0;                         // frames in the block-CMS window (src/io/opts.cc:270-271)
     bool stat_cmvn = false, apply_cmvn = false;
     std::string fcmvn_stat_out, fcmvn_stat_in;
     int d_win = 2, a_win = 2, t_win = 2;

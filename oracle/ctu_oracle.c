@@ -36,6 +36,7 @@ typedef struct {
     int fea_lporder, fea_ncepcoefs, fea_c0, fea_E, fea_rawenergy, fea_lifter;
     int fea_trapdct_traplen, fea_trapdct_ndct;
     float fea_Z_exp, fea_Z_block;
+    int length_b;
     int stat_cmvn, apply_cmvn, d_win, a_win, t_win, fea_delta, n_order, fea_trap, trap_win, nfeacoefs;
     char preset[64];
     char vad_apply_mode[64], vad_out_mode[64], vad_out[1024], vad_cri_mode[64], vad_thr_mode[64];
@@ -392,6 +393,9 @@ static int opts_check_config(ctuo_t *c) {
     for (int i = 1048576; i > 4; i /= 2)
         if ((o->window / i) == 1) o->wfft = i * (1 + ((o->window % i) != 0));
     o->wfftby2 = o->wfft / 2 + 1;
+    /* CMS constants, src/io/opts.cc:270-274 (the float field is overwritten by the forgetting factor) */
+    if (o->fea_Z_block != -1) o->length_b = (int)floor((o->fea_Z_block - o->window_ms) / o->wshift_ms) + 1;
+    if (o->fea_Z_exp != -1) o->fea_Z_exp = (float)1 - (2 * o->wshift_ms) / o->fea_Z_exp;
     /* natural_little is true on every target of this build */
     o->swap_in = (o->endian_in_little == 1) ^ 1;
     o->swap_out = (o->endian_out_little == 1) ^ 1;
@@ -715,9 +719,17 @@ static int design_all(ctuo_t *c) {
         set_err(c, "oracle: nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221); not restated");
         return -1;
     }
-    if (o->stat_cmvn || o->apply_cmvn || o->fea_Z_exp > 0 || o->fea_Z_block > 0) {
-        set_err(c, "oracle: CMVN / CMS post-processing is outside the restated path");
+    if (o->stat_cmvn || o->apply_cmvn) {
+        set_err(c, "oracle: CMVN post-processing is outside the restated path");
         return -1;
+    }
+    if (o->fea_Z_exp > 0 || o->fea_Z_block > 0) { /* row N2, CMS part: src/fea/post_impl.cc:159-240 */
+        if (strcmp(o->fea_kind, "dctc") && strcmp(o->fea_kind, "lpc")) {
+            set_err(c, "oracle: CMS on non-cepstral kinds is not restated (cms_POST walks fea_ncepcoefs+1 entries whatever the vector holds, post_impl.cc:203-240)");
+            return -1;
+        }
+        if (o->fea_trap) { set_err(c, "oracle: CMS on stacked vectors is not restated (it would subtract a mean from the first fea_ncepcoefs+1 context slots only)"); return -1; }
+        if (o->fea_Z_block > 0 && o->length_b < 1) { set_err(c, "oracle: -fea_Z_block shorter than one frame (the reference allocates a ring of length_b <= 0 rows)"); return -1; }
     }
     if (o->fea_delta || o->fea_trap) { /* row N1: restated for the layouts the reference writes completely */
         if (strcmp(o->fea_kind, "dctc") && strcmp(o->fea_kind, "lpc")) {
@@ -782,6 +794,10 @@ static int design_all(ctuo_t *c) {
             if (w[j] < 1) { set_err(c, o->fea_trap ? "FEA: Trap window size must be >= 3!" : "FEA: Delta window size must be > 1!"); return -1; }
         c->Xsize = o->fea_trap ? fea_c * (2 * o->d_win + 1) : fea_c * (o->n_order + 1);
         if (c->do_vad) { set_err(c, "oracle: VAD together with delta / stacking is not restated (the detector would run on delayed and on flushed frames, batch.cc:230-241,251-291)"); return -1; }
+    }
+    if ((o->fea_Z_exp > 0 || o->fea_Z_block > 0) && c->do_vad) {
+        set_err(c, "oracle: VAD together with CMS is not restated");
+        return -1;
     }
     int size = c->Xsize;
     if (!strcmp(k, "lpa")) size -= 1;
@@ -1026,6 +1042,48 @@ static void emit_row(const ctuo_t *c, const double *X, double E, float *row) {
     }
 }
 
+/* ------------------------------------------------------------------ cms_POST (src/fea/post_impl.cc:159-240)
+ * Running cepstral mean over the first fea_ncepcoefs+1 entries of the vector OUT is about to write.  The mean and the
+ * block ring are `float` in the reference, the vector is double; BATCH resets the state per file (batch.cc:388-392). */
+typedef struct {
+    int type;      /* 0 off, 1 exp, 2 block (block wins when both are set, post_impl.cc:163-167) */
+    int n, L, num_frame;
+    float *sumM, *ring;
+} cms_t;
+
+static void cms_init(cms_t *m, const opts_t *o) {
+    memset(m, 0, sizeof *m);
+    if (o->fea_Z_exp > 0) m->type = 1;
+    if (o->fea_Z_block > 0) m->type = 2;
+    if (!m->type) return;
+    m->n = o->fea_ncepcoefs + 1;
+    m->L = o->length_b > 0 ? o->length_b : 1;
+    m->sumM = calloc(m->n, sizeof(float));
+    m->ring = calloc((size_t)m->L * m->n, sizeof(float));
+}
+
+static void cms_free(cms_t *m) { free(m->sumM); free(m->ring); }
+
+static void cms_apply(cms_t *m, const opts_t *o, double *F) {
+    if (m->type == 1) { /* post_impl.cc:207-212 */
+        for (int i = 0; i < m->n; i++) {
+            m->sumM[i] = m->sumM[i] * (o->fea_Z_exp) + F[i] * (1 - o->fea_Z_exp);
+            F[i] -= m->sumM[i];
+        }
+    } else if (m->type == 2) { /* post_impl.cc:214-236 */
+        int x = m->num_frame % m->L;
+        for (int j = 0; j < m->n; j++) m->ring[(size_t)x * m->n + j] = F[j];
+        if (m->num_frame >= m->L - 1) {
+            for (int i = 0; i < m->n; i++) m->sumM[i] = 0;
+            for (int i = 0; i < m->n; i++)
+                for (int xx = 0; xx < m->L; xx++) m->sumM[i] += m->ring[(size_t)xx * m->n + i];
+            for (int i = 0; i < m->n; i++) m->sumM[i] /= m->L;
+        }
+        for (int i = 0; i < m->n; i++) F[i] -= m->sumM[i];
+    }
+    m->num_frame++;
+}
+
 /* ------------------------------------------------------------------ deltaFEA (src/fea/fea_delta.cc)
  * One stage of the chain BATCH::init_delta builds (batch.cc:122-125).  The reference runs it as a streaming
  * ring of 2w+1 input vectors; the ring, its priming (first frame w times, second frame twice) and the flush
@@ -1151,6 +1209,8 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
             return -1;
         }
     }
+    cms_t cms;
+    cms_init(&cms, o);
     /* the circular buffer of in.cc is kept here as a linear double copy of the signal;
      * remove_dc1 mutates it persistently exactly as cbuffer is mutated (in.cc:343-350). */
     double *x = malloc(sizeof(double) * (nsamples > 0 ? nsamples : 1));
@@ -1366,6 +1426,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         E_last = E_out;
         /* ---- BATCH::save_frame, batch.cc:230-241 */
         if (!do_vad) {
+            if (cms.type) cms_apply(&cms, o, fvec); /* BATCH::cmvn_stat, batch.cc:198-200: post, then save */
             emit_row(c, fvec, E_out, rows + (size_t)nrows * c->D);
             nrows++;
             continue;
@@ -1461,7 +1522,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         if (n >= 3) dstage_init(&st[2], o, st[1].out, 4, o->t_win);
         const double *X = st[n - 1].out;
         double E_cur = -1.;
-#define POST_EMIT() do { emit_row(c, X, E_cur, rows + (size_t)nrows * c->D); nrows++; } while (0)
+#define POST_EMIT() do { if (cms.type) cms_apply(&cms, o, (double *)X); emit_row(c, X, E_cur, rows + (size_t)nrows * c->D); nrows++; } while (0)
         for (long t = 0; t < T; t++) {
             memcpy(in0, postbuf + (size_t)t * c->nfea, sizeof(double) * c->nfea);
             E_cur = postE[t];
@@ -1514,6 +1575,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
 
     free(x); free(fft_in); free(Xre); free(Xim); free(zr); free(zi); free(Xabs); free(Xph); free(Y); free(fvec);
     free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin); free(postbuf); free(postE);
+    cms_free(&cms);
     free(RRe); free(rc); free(a); free(aa); free(P);
     free(vs.history); free(vs.ring); free(vs.c0); free(vs.ci); free(hw1); free(hw2); free(tsig); free(hre); free(him);
     return fail ? -1 : nrows;

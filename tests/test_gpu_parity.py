@@ -243,3 +243,25 @@ def test_delta_too_few_frames_is_an_input_error(Engine):
     with pytest.raises(CtuError, match="fewer than window"):
         eng.extract([synth_utt(1, 240 + 160 * 5)])
     assert eng.extract([synth_utt(1, 240 + 160 * 6)])[0].shape == (6, 26)
+
+
+# ---- row N2, CMS part (src/fea/post_impl.cc:159-240)
+@pytest.mark.parametrize("extra", [["-fea_Z_exp", "2000"], ["-fea_Z_exp", "300"], ["-fea_Z_block", "2000"], ["-fea_Z_block", "100"],
+                                   ["-fea_Z_block", "5000"], ["-fea_Z_exp", "500", "-fea_E", "on"],
+                                   ["-fea_Z_block", "500", "-fea_c0", "off"], ["-fea_Z_block", "300", "-fea_delta", "d_a", "-fea_E", "on"],
+                                   ["-fea_Z_exp", "1000", "-fea_delta", "d"]])
+def test_cms(Engine, extra):
+    # CMS output is mean-free, so |ref| is mostly below 1 and the tolerance acts as an absolute 1e-4 on values whose
+    # inputs (c0 ~ 60) carry ~4e-6 of float rounding each; the reference itself keeps the mean in float
+    _check(Engine, C2 + extra, _post_utts())
+
+
+def test_cms_after_exten(Engine):
+    # the fp32 exten recurrence leaves ~1e-4 absolute on c0 (~1.7e-6 of its magnitude, inside the bound of
+    # test_exten_16k); once the mean is gone that same absolute error is measured against |ref| < 1, hence 2e-4 here
+    _check(Engine, C2 + ["-nr_mode", "exten", "-fea_Z_exp", "1000"], _post_utts(), tol=2e-4)
+
+
+def test_cms_on_plp(Engine):
+    _check(Engine, C3 + ["-fea_Z_block", "300"], [sig("CS0"), synth_utt(5, 30000)])
+    _check(Engine, C3 + ["-fea_Z_exp", "300", "-fea_delta", "d_a"], [sig("CS3"), synth_utt(6, 40000)])

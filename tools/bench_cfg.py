@@ -9,7 +9,8 @@ from ctucopy_amd import Engine, shard
 from tests.util import C2, C3, C4, C4_NOVAD, C5
 
 CFGS = {"C2": C2, "C3": C3, "C4": C4, "C4_novad": C4_NOVAD, "C5": C5, "C2_d_a": C2 + ["-fea_delta", "d_a"],
-        "C2_trap9": C2 + ["-fea_trap", "9"]}
+        "C2_trap9": C2 + ["-fea_trap", "9"], "C2_cms_exp": C2 + ["-fea_Z_exp", "2000"], "C2_cms_block": C2 + ["-fea_Z_block", "2000"],
+        "C2_d_a_cms": C2 + ["-fea_delta", "d_a", "-fea_Z_block", "2000"]}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="C3")
 ap.add_argument("--utts", type=int, default=2000)
