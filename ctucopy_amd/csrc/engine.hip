@@ -1386,12 +1386,15 @@ __global__ __launch_bounds__(256) void cms_block_kernel(const float *__restrict_
         const float f = csm[(t - flo) * nc + c];
         float m = 0.f;
         if (t >= L - 1) {
-            // ring slot x holds the newest frame congruent to x mod L: frame t - ((t - x) mod L)
+            // Ring slot x holds the newest frame congruent to x mod L, and the reference adds slots 0..L-1 in that
+            // order: first the frames of the current ring cycle, t - t%L .. t, then the tail of the previous cycle,
+            // t-L+1 .. t - t%L - 1.  Same order here, so the float sum rounds the same way.
             const int tm = t % L;
-            for (int x = 0; x < L; x++) {
-                const int back = tm >= x ? tm - x : tm - x + L;
-                m += csm[(t - back - flo) * nc + c];
-            }
+            const float *q = csm + (t - tm - flo) * nc + c;
+            for (int i = 0; i <= tm; i++) m += q[i * nc];
+            q = csm + (t - L + 1 - flo) * nc + c;
+            const int n2 = L - 1 - tm;
+            for (int i = 0; i < n2; i++) m += q[i * nc];
             m = m / (float)L;
         }
         rows[(ro + t) * cp.D + c] = f - m;
@@ -1401,6 +1404,54 @@ __global__ __launch_bounds__(256) void cms_block_kernel(const float *__restrict_
             const int tt = e / (cp.Dbase - nc), c = nc + e - tt * (cp.Dbase - nc);
             rows[(ro + t0 + tt) * cp.D + c] = base[(ro + t0 + tt) * cp.Dbase + c];
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row N2, CMVN part (src/fea/post_impl.cc:51-118).  One workgroup per 64-frame chunk; thread = statistic slot.
+// HBM-bound: every row is read once per pass (coalesced: consecutive slots are consecutive columns but for the rotated
+// c0 entries), partial sums in double, one fp64 atomic per (chunk, slot).
+__global__ __launch_bounds__(128) void cmvn_accumulate_kernel(const float *__restrict__ rows, const int4 *__restrict__ utt_info,
+                                                              const int *__restrict__ chunks, const int *__restrict__ spk_of_utt,
+                                                              const int *__restrict__ col_of_slot, const double *__restrict__ mean,
+                                                              double *__restrict__ acc, int cols, int D) {
+    const int u = chunks[2 * blockIdx.x], t0 = chunks[2 * blockIdx.x + 1];
+    const int4 ui = utt_info[u];
+    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+    const int n = min(64, ui.z - t0), spk = spk_of_utt[u];
+    for (int k = threadIdx.x; k < cols; k += 128) {
+        const float *src = rows + (ro + t0) * D + col_of_slot[k];
+        double sum = 0.0;
+        if (mean) {
+            const double m = mean[(size_t)spk * cols + k];
+            for (int t = 0; t < n; t++) {
+                const double dlt = (double)src[(size_t)t * D] - m;
+                sum += dlt * dlt;
+            }
+        } else {
+            for (int t = 0; t < n; t++) sum += (double)src[(size_t)t * D];
+        }
+        atomicAdd(&acc[(size_t)spk * (cols + 1) + k], sum);
+    }
+    if (threadIdx.x == 0) atomicAdd(&acc[(size_t)spk * (cols + 1) + cols], (double)n);
+}
+
+__global__ __launch_bounds__(256) void cmvn_apply_kernel(float *__restrict__ rows, const int4 *__restrict__ utt_info,
+                                                         const int *__restrict__ chunks, const int *__restrict__ spk_of_utt,
+                                                         const int *__restrict__ slot_of_col, const double *__restrict__ mean,
+                                                         const double *__restrict__ var, int cols, int D) {
+    const int u = chunks[2 * blockIdx.x], t0 = chunks[2 * blockIdx.x + 1];
+    const int4 ui = utt_info[u];
+    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+    const int n = min(64, ui.z - t0), spk = spk_of_utt[u];
+    float *dst = rows + (ro + t0) * D;
+    for (int e = threadIdx.x; e < n * D; e += 256) {
+        const int t = e / D, c = e - t * D;
+        const int k = slot_of_col[c];
+        if (k >= 0) {
+            const double m = mean[(size_t)spk * cols + k], v = var[(size_t)spk * cols + k];
+            dst[e] = (float)(((double)dst[e] - m) / v);
+        }
+    }
 }
 
 struct ctu_engine {
@@ -1419,6 +1470,10 @@ struct ctu_engine {
     bool timed = false;
     DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
     DevBuf<float> base_rows;  // front-end rows ahead of the delta / stacking pass, sized by the largest plan seen
+    // CMVN (row N2): statistic slot <-> row column maps, and per-call scratch
+    std::vector<int> col_of_slot, slot_of_col;
+    DevBuf<int> d_col_of_slot, d_slot_of_col, d_spk;
+    DevBuf<double> d_stat_a, d_stat_b;
     DevBuf<unsigned long long> stamps;
     bool do_vad = false;
     VadParams vp;
@@ -1468,7 +1523,13 @@ std::string unsupported_reason(const ctu::Design &d) {
         }
         if (wsum > 24) return "delta windows adding up to more than 24 frames (LDS tile of the chain)";
     }
-    if (o.stat_cmvn || o.apply_cmvn) return "per-speaker CMVN (next row N2, second part)";
+    if (o.stat_cmvn || o.apply_cmvn) {
+        if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "CMVN on non-cepstral kinds";
+        if (!o.fea_c0) return "CMVN without -fea_c0 (c0 is part of the statistics but not of the written row)";
+        if (d.post_stack) return "CMVN on stacked vectors";
+        if (d.cms) return "CMVN together with CMS (the reference warns and lets CMVN win, src/io/opts.cc:262-264)";
+        if (o.do_vad()) return "VAD together with CMVN";
+    }
     if (d.cms) {
         if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "CMS on non-cepstral kinds (the reference walks fea_ncepcoefs+1 entries whatever the vector holds, src/fea/post_impl.cc:203-240)";
         if (d.post_stack) return "CMS on stacked vectors";
@@ -2027,7 +2088,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
                 pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
-        if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0 || d.cms) {
+        if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0 || d.cms || d.o.stat_cmvn || d.o.apply_cmvn) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
             pl->n_trap_chunks = (int)chunks.size() / 2;
@@ -2258,6 +2319,139 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl, const int16_t *h_pcm,
         return CTU_ERR_DEVICE;
     }
     return CTU_OK;
+}
+
+static void cmvn_maps(ctu_engine *e) {
+    if (!e->col_of_slot.empty()) return;
+    const ctu::Design &d = *e->design;
+    const int fc = d.o.fea_ncepcoefs + 1, X = fc * (d.post_order + 1);
+    e->col_of_slot.assign(X, 0);
+    e->slot_of_col.assign(d.D, -1);
+    for (int k = 0; k < X; k++) {
+        const int i = (k + 1) % X;               // internal vector entry held by slot k (post_impl.cc:56-62)
+        const int j = i / fc, ii = i % fc;       // block, entry within the block (0 = c0)
+        const int col = fc * j + (ii == 0 ? fc - 1 : ii - 1);  // writer order: c1..cN, c0 (out.cc:188-201)
+        e->col_of_slot[k] = col;
+        e->slot_of_col[col] = k;
+    }
+    e->d_col_of_slot.upload(e->col_of_slot);
+    e->d_slot_of_col.upload(e->slot_of_col);
+}
+
+static int cmvn_check(ctu_engine *e, const ctu_plan *pl, const int32_t *spk_of_utt, int32_t n_spk) {
+    if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
+    const ctu::Design &d = *e->design;
+    if (!(d.o.stat_cmvn || d.o.apply_cmvn)) {
+        set_error(e, "ENGINE: engine was not created with -stat_cmvn / -apply_cmvn");
+        return CTU_ERR_INPUT;
+    }
+    if (n_spk < 1 || (pl->n_utt && !spk_of_utt)) {
+        set_error(e, "ENGINE: speaker table missing");
+        return CTU_ERR_INPUT;
+    }
+    for (int i = 0; i < pl->n_utt; i++)
+        if (spk_of_utt[i] < 0 || spk_of_utt[i] >= n_spk) {
+            set_error(e, "ENGINE: speaker index out of range");
+            return CTU_ERR_INPUT;
+        }
+    return CTU_OK;
+}
+
+int ctu_cmvn_cols(const ctu_engine *e) {
+    if (!e) return -1;
+    const ctu::Design &d = *e->design;
+    return (d.o.fea_ncepcoefs + 1) * (d.post_order + 1);
+}
+
+int ctu_cmvn_accumulate(ctu_engine *e, const ctu_plan *pl, const float *d_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                        const double *mean, double *acc, void *stream) {
+    int rc = cmvn_check(e, pl, spk_of_utt, n_spk);
+    if (rc != CTU_OK) return rc;
+    if (!acc || (pl->total_frames && !d_rows)) return CTU_ERR_INPUT;
+    if (pl->total_frames == 0) return CTU_OK;
+    hipStream_t s = (hipStream_t)stream;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        cmvn_maps(e);
+        const int cols = ctu_cmvn_cols(e);
+        std::vector<int> spk(spk_of_utt, spk_of_utt + pl->n_utt);
+        e->d_spk.upload(spk);
+        std::vector<double> zero((size_t)n_spk * (cols + 1), 0.0);
+        e->d_stat_a.upload(zero);
+        if (mean) e->d_stat_b.upload(std::vector<double>(mean, mean + (size_t)n_spk * cols));
+        hipLaunchKernelGGL(cmvn_accumulate_kernel, dim3(pl->n_trap_chunks), dim3(128), 0, s, d_rows, pl->utt_info.p,
+                           pl->trap_chunks.p, e->d_spk.p, e->d_col_of_slot.p, mean ? e->d_stat_b.p : nullptr, e->d_stat_a.p,
+                           cols, e->design->D);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(zero.data(), e->d_stat_a.p, zero.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < zero.size(); i++) acc[i] += zero[i];
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
+    return CTU_OK;
+}
+
+int ctu_cmvn_apply(ctu_engine *e, const ctu_plan *pl, float *d_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                   const double *mean, const double *var, void *stream) {
+    int rc = cmvn_check(e, pl, spk_of_utt, n_spk);
+    if (rc != CTU_OK) return rc;
+    if (!mean || !var || (pl->total_frames && !d_rows)) return CTU_ERR_INPUT;
+    if (pl->total_frames == 0) return CTU_OK;
+    hipStream_t s = (hipStream_t)stream;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        cmvn_maps(e);
+        const int cols = ctu_cmvn_cols(e);
+        std::vector<int> spk(spk_of_utt, spk_of_utt + pl->n_utt);
+        e->d_spk.upload(spk);
+        e->d_stat_a.upload(std::vector<double>(mean, mean + (size_t)n_spk * cols));
+        e->d_stat_b.upload(std::vector<double>(var, var + (size_t)n_spk * cols));
+        hipLaunchKernelGGL(cmvn_apply_kernel, dim3(pl->n_trap_chunks), dim3(256), 0, s, d_rows, pl->utt_info.p,
+                           pl->trap_chunks.p, e->d_spk.p, e->d_slot_of_col.p, e->d_stat_a.p, e->d_stat_b.p, cols, e->design->D);
+        HIP_TRY(hipGetLastError());
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
+    return CTU_OK;
+}
+
+int ctu_cmvn_accumulate_host(ctu_engine *e, const ctu_plan *pl, const float *h_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                             const double *mean, double *acc) {
+    if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
+    if (pl->total_frames == 0) return CTU_OK;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        DevBuf<float> rows;
+        rows.alloc((size_t)pl->total_frames * e->design->D);
+        HIP_TRY(hipMemcpy(rows.p, h_rows, rows.n * sizeof(float), hipMemcpyHostToDevice));
+        return ctu_cmvn_accumulate(e, pl, rows.p, spk_of_utt, n_spk, mean, acc, nullptr);
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
+}
+
+int ctu_cmvn_apply_host(ctu_engine *e, const ctu_plan *pl, float *h_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                        const double *mean, const double *var) {
+    if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
+    if (pl->total_frames == 0) return CTU_OK;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        DevBuf<float> rows;
+        rows.alloc((size_t)pl->total_frames * e->design->D);
+        HIP_TRY(hipMemcpy(rows.p, h_rows, rows.n * sizeof(float), hipMemcpyHostToDevice));
+        const int rc = ctu_cmvn_apply(e, pl, rows.p, spk_of_utt, n_spk, mean, var, nullptr);
+        if (rc != CTU_OK) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h_rows, rows.p, rows.n * sizeof(float), hipMemcpyDeviceToHost));
+        return CTU_OK;
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
 }
 
 float ctu_engine_last_kernel_ms(ctu_engine *e) {

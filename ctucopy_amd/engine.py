@@ -30,7 +30,8 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_engine_last_kernel_ms"]
+           "ctu_engine_run_host", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host"]
 
 _lib = None
 
@@ -72,6 +73,11 @@ def load_library():
     L.ctu_engine_run_host.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_last_kernel_ms.restype = ctypes.c_float
     L.ctu_engine_last_kernel_ms.argtypes = [vp]
+    L.ctu_cmvn_cols.argtypes = [vp]
+    L.ctu_cmvn_accumulate.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    L.ctu_cmvn_apply.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    L.ctu_cmvn_accumulate_host.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.ctu_cmvn_apply_host.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     _lib = L
     return L
 
@@ -194,6 +200,34 @@ class Engine:
                                                        vad.ctypes.data if self.dims.has_vad else None, per.ctypes.data))
         if want_vad:
             return rows, vad[:plan.total_frames], per
+        return rows
+
+    # ---- per-speaker CMVN over device-resident rows (include/ctu_engine.h; src/fea/post_impl.cc:51-118)
+    def cmvn_cols(self):
+        return int(load_library().ctu_cmvn_cols(self._h))
+
+    def cmvn_accumulate(self, plan, rows, spk_of_utt, n_spk, mean=None, acc=None, stream=None):
+        """acc[n_spk, cols+1] (float64) += sums (mean is None) or sums of squared deviations from `mean`, and counts."""
+        import torch
+        cols = self.cmvn_cols()
+        spk = np.ascontiguousarray(spk_of_utt, dtype=np.int32)
+        if acc is None:
+            acc = np.zeros((n_spk, cols + 1), dtype=np.float64)
+        assert acc.shape == (n_spk, cols + 1) and acc.dtype == np.float64 and acc.flags.c_contiguous
+        m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+        s = stream if stream is not None else torch.cuda.current_stream(rows.device)
+        self._check(load_library().ctu_cmvn_accumulate(self._h, plan._h, rows.data_ptr(), spk.ctypes.data, int(n_spk),
+                                                       m.ctypes.data if m is not None else None, acc.ctypes.data, s.cuda_stream))
+        return acc
+
+    def cmvn_apply(self, plan, rows, spk_of_utt, n_spk, mean, var, stream=None):
+        import torch
+        spk = np.ascontiguousarray(spk_of_utt, dtype=np.int32)
+        m = np.ascontiguousarray(mean, dtype=np.float64)
+        v = np.ascontiguousarray(var, dtype=np.float64)
+        s = stream if stream is not None else torch.cuda.current_stream(rows.device)
+        self._check(load_library().ctu_cmvn_apply(self._h, plan._h, rows.data_ptr(), spk.ctypes.data, int(n_spk),
+                                                  m.ctypes.data, v.ctypes.data, s.cuda_stream))
         return rows
 
     def last_kernel_ms(self):

@@ -302,6 +302,10 @@ int real_main(int argc, char **argv) {
             }
             ss >> it.spk >> it.fvad;
             if (o.do_vad() && it.fvad.empty()) throw Fatal("BATCH: Bad list format!");
+            // CMVN lists (src/io/batch.cc:358-367): "<in> <speaker>" when only statistics are wanted,
+            // "<in> <out> <speaker>" when they are applied
+            if (o.apply_cmvn && it.spk.empty()) throw Fatal(" Bad list format for applying cmvn!");
+            if (o.stat_cmvn && it.spk.empty()) it.spk = it.fout;
             items.push_back(it);
         }
     }
@@ -324,6 +328,23 @@ int real_main(int argc, char **argv) {
         if (o.fea_kind == "lpa") nfea_pf += 1;
         pf.reset(new PfileWriter(o.pfilename, nfea_pf));
     }
+
+    // ---- per-speaker CMVN (src/io/batch.cc:131-171,331-419).  -apply_cmvn <f>: the reference first tries to read <f>;
+    // its reader keeps "mean" as every speaker's name and only fea_ncepcoefs+1 values (src/io/in.cc:735-770), after
+    // which add_spk allocates fresh all-zero statistics for each real speaker - the run divides by zero.  That path is
+    // not reproduced.  When <f> does not exist the reference computes the statistics, writes them to <f> and applies
+    // them in a third pass; -stat_cmvn <f> alone computes and writes them and produces no feature files.
+    const bool cmvn = o.stat_cmvn || o.apply_cmvn;
+    std::string stat_path = o.fcmvn_stat_out;
+    if (o.apply_cmvn) {
+        if (std::ifstream(o.fcmvn_stat_in).good())
+            throw Fatal("ENGINE: applying an existing CMVN statistics file is not on the accelerated path (the reference's "
+                        "reader loses the speaker names and the statistics, src/io/in.cc:735-770)");
+        std::printf("IN: Cannot open stat. cmvn file!\nIN: Stat. cmvn file is being created: %s\n", o.fcmvn_stat_in.c_str());
+        stat_path = o.fcmvn_stat_in;
+    }
+    std::vector<std::vector<float>> all_rows(cmvn ? items.size() : 0);
+    std::vector<int64_t> all_ns(cmvn ? items.size() : 0);
 
     const size_t batch_samples = 512u << 20;  // ~1 GiB of PCM per batch
     size_t pos = 0;
@@ -371,6 +392,11 @@ int real_main(int argc, char **argv) {
             const Item &it = items[pos + i];
             const int64_t nr = (int64_t)rows[i].size() / d.row_floats;
             if (o.verbose) std::fprintf(stderr, "processing: %s - %lld frames.\n", it.fin.c_str(), (long long)nr);
+            if (cmvn) {  // rows wait for the corpus statistics
+                all_rows[pos + i] = std::move(rows[i]);
+                all_ns[pos + i] = (int64_t)pcm[i].size();
+                continue;
+            }
             if (d.has_vad && o.vad_out_mode != "none") {  // one ASCII '0'/'1' per frame (src/vad/vad.h:67-70)
                 if (it.fvad.empty()) throw Fatal("VAD::new_file(): invalid filename!");
                 write_file(it.fvad, std::vector<uint8_t>(vads[i].begin(), vads[i].end()), "FileWriter: cannot open file!");
@@ -386,6 +412,114 @@ int real_main(int argc, char **argv) {
             }
         }
         pos = end;
+    }
+    if (cmvn) {
+        // speaker table in order of first appearance (cmvn_POST::add_spk, src/fea/post_impl.cc:120-142)
+        std::vector<std::string> spk_names;
+        std::vector<int32_t> spk_of(items.size());
+        for (size_t i = 0; i < items.size(); i++) {
+            auto f = std::find(spk_names.begin(), spk_names.end(), items[i].spk);
+            spk_of[i] = (int32_t)(f - spk_names.begin());
+            if (f == spk_names.end()) spk_names.push_back(items[i].spk);
+        }
+        const int n_spk = (int)spk_names.size(), cols = ctu_cmvn_cols(gpus[0].eng);
+        // shards over the whole corpus; every GPU keeps its rows in one block behind a plan with the same geometry
+        struct Shard {
+            std::vector<size_t> idx;
+            std::vector<int32_t> spk;
+            std::vector<float> rows;
+            ctu_plan *plan = nullptr;
+        };
+        std::vector<Shard> sh(ngpu);
+        {
+            std::vector<size_t> load(ngpu, 0);
+            for (size_t i = 0; i < items.size(); i++) {
+                const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                sh[g].idx.push_back(i);
+                load[g] += all_rows[i].size();
+            }
+        }
+        for (int g = 0; g < ngpu; g++) {
+            std::vector<int64_t> ns;
+            for (size_t i : sh[g].idx) {
+                ns.push_back(all_ns[i]);
+                sh[g].spk.push_back(spk_of[i]);
+                sh[g].rows.insert(sh[g].rows.end(), all_rows[i].begin(), all_rows[i].end());
+                std::vector<float>().swap(all_rows[i]);
+            }
+            if (ctu_plan_create(gpus[g].eng, ns.data(), (int)ns.size(), &sh[g].plan) != CTU_OK) throw Fatal(ctu_last_error(gpus[g].eng));
+        }
+        auto reduce = [&](const double *mean) {  // one pass over every GPU's rows, partial sums added on the host
+            std::vector<double> acc((size_t)n_spk * (cols + 1), 0.0);
+            std::vector<std::vector<double>> part(ngpu, acc);
+            std::vector<std::string> errs(ngpu);
+            std::vector<std::thread> th;
+            for (int g = 0; g < ngpu; g++)
+                th.emplace_back([&, g] {
+                    if (sh[g].idx.empty()) return;
+                    if (ctu_cmvn_accumulate_host(gpus[g].eng, sh[g].plan, sh[g].rows.data(), sh[g].spk.data(), n_spk, mean,
+                                                 part[g].data()) != CTU_OK)
+                        errs[g] = ctu_last_error(gpus[g].eng);
+                });
+            for (auto &t : th) t.join();
+            for (auto &e : errs)
+                if (!e.empty()) throw Fatal(e);
+            for (int g = 0; g < ngpu; g++)
+                for (size_t k = 0; k < acc.size(); k++) acc[k] += part[g][k];
+            return acc;
+        };
+        std::vector<double> mean((size_t)n_spk * cols), var((size_t)n_spk * cols);
+        {
+            const std::vector<double> a = reduce(nullptr);  // sum_fea + stat_cm (post_impl.cc:51-76)
+            for (int s_ = 0; s_ < n_spk; s_++)
+                for (int k = 0; k < cols; k++) mean[(size_t)s_ * cols + k] = a[(size_t)s_ * (cols + 1) + k] / a[(size_t)s_ * (cols + 1) + cols];
+            const std::vector<double> b = reduce(mean.data());  // sum_cv + stat_cv (post_impl.cc:78-102)
+            for (int s_ = 0; s_ < n_spk; s_++)
+                for (int k = 0; k < cols; k++) var[(size_t)s_ * cols + k] = b[(size_t)s_ * (cols + 1) + k] / (b[(size_t)s_ * (cols + 1) + cols] - 1);
+        }
+        {  // cmvnOUT::save_frame (src/io/out.cc:591-613)
+            FILE *f = std::fopen(stat_path.c_str(), "wt");
+            if (!f) throw Fatal("OUT: Cannot create output file with stat. of cmvn!");
+            for (int s_ = 0; s_ < n_spk; s_++) {
+                std::fprintf(f, "%s\nmean\t", spk_names[s_].c_str());
+                for (int k = 0; k < cols; k++) std::fprintf(f, k + 1 < cols ? "%f " : "%f", mean[(size_t)s_ * cols + k]);
+                std::fprintf(f, "\nvar\t");
+                for (int k = 0; k < cols; k++) std::fprintf(f, k + 1 < cols ? "%f " : "%f\n", var[(size_t)s_ * cols + k]);
+            }
+            std::fclose(f);
+        }
+        if (o.apply_cmvn) {
+            std::vector<std::string> errs(ngpu);
+            std::vector<std::thread> th;
+            for (int g = 0; g < ngpu; g++)
+                th.emplace_back([&, g] {
+                    if (sh[g].idx.empty()) return;
+                    if (ctu_cmvn_apply_host(gpus[g].eng, sh[g].plan, sh[g].rows.data(), sh[g].spk.data(), n_spk, mean.data(),
+                                            var.data()) != CTU_OK)
+                        errs[g] = ctu_last_error(gpus[g].eng);
+                });
+            for (auto &t : th) t.join();
+            for (auto &e : errs)
+                if (!e.empty()) throw Fatal(e);
+            // back to list order, then the writers
+            std::vector<std::pair<int, size_t>> where(items.size());  // (gpu, row offset in floats)
+            for (int g = 0; g < ngpu; g++) {
+                const int64_t *ro = ctu_plan_row_offsets(sh[g].plan);
+                for (size_t k = 0; k < sh[g].idx.size(); k++) where[sh[g].idx[k]] = {g, (size_t)ro[k] * d.row_floats};
+            }
+            for (size_t i = 0; i < items.size(); i++) {
+                const int g = where[i].first;
+                const int64_t *ro = ctu_plan_row_offsets(sh[g].plan);
+                const size_t k = std::find(sh[g].idx.begin(), sh[g].idx.end(), i) - sh[g].idx.begin();
+                const int64_t nr = ro[k + 1] - ro[k];
+                const float *r = sh[g].rows.data() + where[i].second;
+                if (ark) ark->add(items[i].fout, r, nr, d.row_floats);
+                else if (pf) pf->add(r, nr, d.row_floats);
+                else write_htk(items[i].fout, r, nr, d);
+            }
+        }
+        for (auto &x : sh)
+            if (x.plan) ctu_plan_destroy(x.plan);
     }
     if (pf) pf->close();
     return 0;

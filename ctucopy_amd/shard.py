@@ -2,6 +2,8 @@
 
 Utterances are independent on the hot path, so N ranks = N independent shards and NO collective touches the data;
 torch.distributed (RCCL on GPUs, gloo in the CPU tests) only carries the timing barrier, max(time), sum(frames).
+The one real exchange step of the tool is per-speaker CMVN (row N2): a speaker's utterances may sit on several ranks,
+so the [n_spk, cols+1] partial sums of each statistics pass are all-reduced (allreduce_stats).
 """
 import numpy as np
 
@@ -40,3 +42,20 @@ def reduce_timing(dt_seconds, frames, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     return float(t.item()), float(f.item())
+
+
+def allreduce_stats(acc, device=None):
+    """Sum the per-speaker partial statistics of Engine.cmvn_accumulate over ranks, in place (float64, [n_spk, cols+1]).
+
+    One small all-reduce per statistics pass (RCCL when `device` is a GPU, gloo on CPU); identity without a process
+    group.  Every rank must hold the same speaker table (the list's order of first appearance)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return acc
+    t = torch.from_numpy(acc)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    acc[...] = t.cpu().numpy()
+    return acc

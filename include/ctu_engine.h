@@ -106,6 +106,35 @@ int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, fl
  * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */
 float ctu_engine_last_kernel_ms(ctu_engine *);
 
+/* ---- per-speaker CMVN over rows that are resident on the device -----------------------------------------------
+ * Replaces cmvn_POST::sum_fea / stat_cm / sum_cv / stat_cv / process_frame (src/fea/post_impl.cc:51-118) and the
+ * three passes over the list that BATCH::process makes for them (src/io/batch.cc:331-419): with the corpus' rows
+ * kept in HBM the passes run over rows, not over audio.  The caller owns the speaker table (add_spk,
+ * post_impl.cc:120-142: list order of first appearance) and, with several GPUs, sums `acc` over ranks.
+ *
+ * Statistics are in the reference's own order (the order of the -stat_cmvn file, src/io/out.cc:591-613):
+ * slot k holds internal vector entry k+1, the last slot holds entry 0 (c0 of the base block); the energy column is
+ * not part of the vector.  ctu_cmvn_cols = number of slots. */
+int ctu_cmvn_cols(const ctu_engine *);
+
+/* acc[n_spk][cols+1] (host, double) += per-speaker sums over the plan's rows and, in the last slot, the frame count.
+ * mean == NULL: sums of the values (pass 1);  mean != NULL ([n_spk][cols]): sums of (value - mean)^2 (pass 2).
+ * Synchronises on `stream`. */
+int ctu_cmvn_accumulate(ctu_engine *, const ctu_plan *, const float *d_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                        const double *mean, double *acc, void *stream);
+
+/* rows = (rows - mean) / var in place - the reference divides by the variance, not by its root
+ * (src/fea/post_impl.cc:104-118).  mean, var: [n_spk][cols] (host, double).  Asynchronous on `stream`. */
+int ctu_cmvn_apply(ctu_engine *, const ctu_plan *, float *d_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                   const double *mean, const double *var, void *stream);
+
+/* Host-buffer conveniences (H2D of the rows, the call above, D2H for apply; synchronised on return) for callers
+ * that hold the rows in host memory, like the `ctucopy` executable. */
+int ctu_cmvn_accumulate_host(ctu_engine *, const ctu_plan *, const float *h_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                             const double *mean, double *acc);
+int ctu_cmvn_apply_host(ctu_engine *, const ctu_plan *, float *h_rows, const int32_t *spk_of_utt, int32_t n_spk,
+                        const double *mean, const double *var);
+
 #ifdef __cplusplus
 }
 #endif

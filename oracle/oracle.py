@@ -154,3 +154,63 @@ def htk_bytes(rows, period, kind, big_endian=False):
     hdr = np.array([n], dtype=e + "u4").tobytes() + np.array([period], dtype=e + "u4").tobytes() + \
         np.array([4 * d], dtype=e + "u2").tobytes() + np.array([kind], dtype=e + "u2").tobytes()
     return hdr + rows.astype(e + "f4").tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-speaker CMVN (row N2): numpy restatement of cmvn_POST (src/fea/post_impl.cc:51-142) and of the three passes
+# BATCH::process makes for it (src/io/batch.cc:331-419).  Works on the rows the oracle emits for the same options
+# without the -stat_cmvn / -apply_cmvn flags (float32 casts of the doubles the reference accumulates).
+def cmvn_slot_columns(ncep, n_blocks):
+    """Row column of statistic slot k.  Slot k holds internal vector entry k+1, the last slot entry 0
+    (post_impl.cc:56-62); entry i of block j sits at row column fc*j + (i-1), c0 (i == 0) at fc*j + fc-1 (out.cc:188-201)."""
+    fc = ncep + 1
+    X = fc * n_blocks
+    cols = []
+    for k in range(X):
+        i = (k + 1) % X
+        j, ii = divmod(i, fc)
+        cols.append(fc * j + (fc - 1 if ii == 0 else ii - 1))
+    return np.array(cols)
+
+
+def cmvn_speakers(ids):
+    """add_spk (post_impl.cc:120-142): speakers are numbered in order of first appearance in the list."""
+    table, out = [], []
+    for s in ids:
+        if s not in table:
+            table.append(s)
+        out.append(table.index(s))
+    return table, np.array(out, dtype=np.int32)
+
+
+def cmvn_stats(rows_by_utt, spk_of_utt, n_spk, slot_cols):
+    """sum_fea + stat_cm, then sum_cv + stat_cv (post_impl.cc:51-102): mean over all frames of a speaker, then the sum
+    of squared deviations from that mean divided by count - 1."""
+    X = len(slot_cols)
+    mean = np.zeros((n_spk, X))
+    count = np.zeros(n_spk)
+    for r, s in zip(rows_by_utt, spk_of_utt):
+        mean[s] += r[:, slot_cols].astype(np.float64).sum(0)
+        count[s] += r.shape[0]
+    mean /= count[:, None]
+    var = np.zeros((n_spk, X))
+    for r, s in zip(rows_by_utt, spk_of_utt):
+        d = r[:, slot_cols].astype(np.float64) - mean[s]
+        var[s] += (d * d).sum(0)
+    var /= (count[:, None] - 1)
+    return mean, var, count
+
+
+def cmvn_apply(rows, spk, mean, var, slot_cols):
+    """process_frame (post_impl.cc:104-118): (F - mean) / var - the variance, not its root."""
+    out = rows.astype(np.float64).copy()
+    out[:, slot_cols] = (out[:, slot_cols] - mean[spk]) / var[spk]
+    return out.astype(np.float32)
+
+
+def cmvn_stat_text(ids, mean, var):
+    """cmvnOUT::save_frame (src/io/out.cc:591-613): "<id>\nmean\t%f %f ...\nvar\t%f ...\n" per speaker."""
+    out = []
+    for i, name in enumerate(ids):
+        out.append("%s\nmean\t%s\nvar\t%s\n" % (name, " ".join("%f" % v for v in mean[i]), " ".join("%f" % v for v in var[i])))
+    return "".join(out)

@@ -196,3 +196,44 @@ def test_delta_and_stacking_headers(tmp_path):
         assert struct.unpack("<IIHH", img[:12]) == (frames, 100000, 65 * 4, base | 0o20000 | 0o400)
         got = np.frombuffer(img[12:], dtype="<f4").reshape(frames, 65)
         assert _close(got, orc.process(sig(name)))
+
+
+@pytest.mark.gpu
+def test_cmvn_statistics_file_and_three_pass_apply(tmp_path):
+    from oracle.oracle import cmvn_apply, cmvn_slot_columns, cmvn_stat_text, cmvn_stats
+    # statistics only: "<in> <speaker>" lines, no feature files (src/io/batch.cc:154-156,358-364)
+    lst = tmp_path / "stat.scp"
+    lst.write_text("".join("%s %s\n" % (os.path.join(GOLDEN, "SA000CB1." + n), s) for n, s in (("CS0", "spkA"), ("CS3", "spkB"), ("CS0", "spkB"))))
+    stat = tmp_path / "cmvn.stat"
+    r = run(C1 + ["-stat_cmvn", str(stat), "-S", str(lst)])
+    assert r.returncode == 0, r.stderr
+    orc = Oracle(C1)
+    rows = [orc.process(sig(n)) for n in ("CS0", "CS3", "CS0")]
+    spk = np.array([0, 1, 1])
+    cols = cmvn_slot_columns(12, 1)
+    mean, var, _ = cmvn_stats(rows, spk, 2, cols)
+    text = stat.read_text()
+    want = cmvn_stat_text(["spkA", "spkB"], mean, var)
+    assert [l.split("\t")[0] for l in text.splitlines()] == [l.split("\t")[0] for l in want.splitlines()]
+    got_vals = np.array([[float(v) for v in l.split("\t")[1].split()] for l in text.splitlines() if "\t" in l])
+    want_vals = np.array([[float(v) for v in l.split("\t")[1].split()] for l in want.splitlines() if "\t" in l])
+    assert got_vals.shape == (4, 13) and np.abs(got_vals - want_vals).max() <= 2e-6 + 1e-6 * np.abs(want_vals).max()
+    assert not list(tmp_path.glob("*.out"))
+    # compute + apply: "<in> <out> <speaker>", statistics land in the -apply_cmvn file (src/io/batch.cc:131-151)
+    lst2 = tmp_path / "apply.scp"
+    lst2.write_text("".join("%s %s %s\n" % (os.path.join(GOLDEN, "SA000CB1." + n), tmp_path / (t + ".out"), s)
+                            for n, t, s in (("CS0", "a", "spkA"), ("CS3", "b", "spkB"), ("CS0", "c", "spkB"))))
+    stat2 = tmp_path / "cmvn2.stat"
+    r = run(C1 + ["-apply_cmvn", str(stat2), "-S", str(lst2)])
+    assert r.returncode == 0, r.stderr
+    assert "Stat. cmvn file is being created" in r.stdout
+    assert stat2.read_text().splitlines()[0] == "spkA"
+    for t, i in (("a", 0), ("b", 1), ("c", 2)):
+        img = (tmp_path / (t + ".out")).read_bytes()
+        n = rows[i].shape[0]
+        assert struct.unpack("<IIHH", img[:12]) == (n, 100000, 52, 8198)
+        got = np.frombuffer(img[12:], dtype="<f4").reshape(n, 13)
+        assert _close(got, cmvn_apply(rows[i], spk[i], mean, var, cols))
+    # an existing statistics file is refused (the reference's reader is broken, see main.cc)
+    r = run(C1 + ["-apply_cmvn", str(stat2), "-S", str(lst2)])
+    assert r.returncode != 0 and "existing CMVN statistics" in r.stderr

@@ -56,3 +56,47 @@ def test_lengths_are_deterministic_and_in_range():
     assert np.array_equal(a, b) and a.min() >= 48000 and a.max() <= 240000
     assert not np.array_equal(a, shard.utterance_lengths(1000, 6))
     assert torch.is_tensor(torch.zeros(1))
+
+
+# ---- per-speaker CMVN: the one exchange step (row N2).  Each rank holds half of the utterances; speakers span ranks.
+def _cmvn_worker(rank, world, port, q):
+    from oracle.oracle import cmvn_slot_columns, cmvn_stats
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    rows = [rng.standard_normal((50 + 10 * i, 13)).astype(np.float32) * (1 + i) + i for i in range(8)]
+    spk = np.array([0, 1, 2, 0, 1, 2, 0, 1], dtype=np.int32)
+    cols = cmvn_slot_columns(12, 1)
+    lo, hi = shard.split_list(len(rows), world, rank)
+    # what Engine.cmvn_accumulate returns for this rank's shard: [n_spk, cols+1] sums and counts
+    def partial(mean):
+        acc = np.zeros((3, 14))
+        for r, s_ in zip(rows[lo:hi], spk[lo:hi]):
+            x = r[:, cols].astype(np.float64)
+            acc[s_, :13] += x.sum(0) if mean is None else ((x - mean[s_]) ** 2).sum(0)
+            acc[s_, 13] += r.shape[0]
+        return acc
+    a = shard.allreduce_stats(partial(None))
+    mean = a[:, :13] / a[:, 13:]
+    b = shard.allreduce_stats(partial(mean))
+    var = b[:, :13] / (b[:, 13:] - 1)
+    ref_mean, ref_var, ref_count = cmvn_stats(rows, spk, 3, cols)
+    q.put((rank, float(np.abs(mean - ref_mean).max()), float(np.abs(var / ref_var - 1).max()), a[:, 13].tolist(), ref_count.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_cmvn_statistics_match_the_single_process_ones():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_cmvn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, dm, dv, counts, ref_counts in res:
+        assert dm < 1e-12 and dv < 1e-12 and counts == ref_counts

@@ -265,3 +265,62 @@ def test_cms_after_exten(Engine):
 def test_cms_on_plp(Engine):
     _check(Engine, C3 + ["-fea_Z_block", "300"], [sig("CS0"), synth_utt(5, 30000)])
     _check(Engine, C3 + ["-fea_Z_exp", "300", "-fea_delta", "d_a"], [sig("CS3"), synth_utt(6, 40000)])
+
+
+# ---- row N2, CMVN part (src/fea/post_impl.cc:51-142, src/io/batch.cc:331-419)
+@pytest.mark.parametrize("extra,blocks", [([], 1), (["-fea_delta", "d_a"], 3), (["-fea_delta", "d", "-fea_E", "on"], 2)])
+def test_cmvn_statistics_and_apply(Engine, extra, blocks):
+    import torch
+    from oracle.oracle import cmvn_apply, cmvn_slot_columns, cmvn_speakers, cmvn_stats
+    cfg = C2 + extra
+    utts = [sig("CS0"), sig("CS3")] + [synth_utt(50 + i, 16000 * (2 + i % 3) + 37 * i) for i in range(6)]
+    names, spk = cmvn_speakers(["anna", "bob", "anna", "cyril", "bob", "anna", "cyril", "dora"])
+    n_spk = len(names)
+    orc = Oracle(cfg)
+    ref_rows = [orc.process(u) for u in utts]
+    slot_cols = cmvn_slot_columns(12, blocks)
+    ref_mean, ref_var, ref_count = cmvn_stats(ref_rows, spk, n_spk, slot_cols)
+
+    eng = Engine(cfg + ["-stat_cmvn", "unused.stat", "-apply_cmvn", "unused.stat"])
+    assert eng.cmvn_cols() == 13 * blocks == len(slot_cols)
+    plan = eng.plan([len(u) for u in utts])
+    pcm = torch.from_numpy(plan.pack(utts)).cuda()
+    rows = eng.run_device(plan, pcm)
+    torch.cuda.synchronize()
+    pre = rows.cpu().numpy()
+    for i, r in enumerate(ref_rows):  # with the CMVN flags the run itself still yields the un-normalised rows
+        assert rel_err(pre[plan.row_off[i]:plan.row_off[i + 1]], r) <= TOL
+    a = eng.cmvn_accumulate(plan, rows, spk, n_spk)
+    assert np.array_equal(a[:, -1], ref_count)
+    mean = a[:, :-1] / a[:, -1:]
+    b = eng.cmvn_accumulate(plan, rows, spk, n_spk, mean=mean)
+    var = b[:, :-1] / (b[:, -1:] - 1)
+    assert np.abs(mean - ref_mean).max() <= 1e-5 * max(1.0, np.abs(ref_mean).max())
+    assert np.abs(var / ref_var - 1).max() <= 1e-4
+    eng.cmvn_apply(plan, rows, spk, n_spk, mean, var)
+    torch.cuda.synchronize()
+    got = rows.cpu().numpy()
+    for i, r in enumerate(ref_rows):
+        want = cmvn_apply(r, spk[i], ref_mean, ref_var, slot_cols)
+        assert rel_err(got[plan.row_off[i]:plan.row_off[i + 1]], want) <= TOL
+    if "-fea_E" in extra:  # the energy column is not part of the vector: untouched
+        assert np.array_equal(got[:, -1], pre[:, -1])
+    # whole-corpus property: every speaker's normalised columns have mean 0 and "variance" 1/var
+    for s_ in range(n_spk):
+        x = np.concatenate([got[plan.row_off[i]:plan.row_off[i + 1]] for i in range(len(utts)) if spk[i] == s_])[:, slot_cols]
+        assert np.abs(x.mean(0) * ref_var[s_]).max() < 1e-3 * np.sqrt(ref_var[s_]).max()
+        assert np.abs(x.var(0, ddof=1) * ref_var[s_] - 1).max() < 1e-3
+
+
+def test_cmvn_argument_checks(Engine):
+    import torch
+    from ctucopy_amd import CtuError
+    eng = Engine(C2)
+    plan = eng.plan([16000])
+    rows = torch.zeros((plan.total_frames, 13), device="cuda")
+    with pytest.raises(CtuError, match="not created with"):
+        eng.cmvn_accumulate(plan, rows, [0], 1)
+    eng = Engine(C2 + ["-stat_cmvn", "x"])
+    plan = eng.plan([16000])
+    with pytest.raises(CtuError, match="out of range"):
+        eng.cmvn_accumulate(plan, rows, [3], 2)
