@@ -108,6 +108,22 @@ Design::Design(const Opts &opts) : o(opts) {
         for (int j = 0; j < window; j++) hamming[j] = 0.54 - (1 - 0.54) * std::cos(2 * pi * j / (window - 1.));
     }
 
+    signal_out = (o.format_out == "raw" || o.format_out == "wave");
+    if (signal_out) {
+        // row N3: no FB, no FEA.  OLA correction = maximum over the phases of the shift of the summed windows
+        // (src/io/out.cc:355-377; pi = 2*asin(1) there too)
+        const double pi = 2. * std::asin(1.);
+        ola_corr = 0.;
+        for (int i = 0; i < wshift; i++) {
+            double y = 0.;
+            for (int x = i; x < window; x += wshift) y += 0.54 - (1 - 0.54) * std::cos(2 * pi * (double)x / (window - 1.));
+            if (y > ola_corr) ola_corr = y;
+        }
+        kind = FeaKind::None;
+        B = 0; nfea = 0; D = Dbase = 0; htk_kind = 0;
+        period = (unsigned)std::floor(.5 + 10000000. * wshift / (double)o.fs);
+        return;
+    }
     // ---- filter bank
     const bool plp = (o.fb_shape == "trapez");
     if (plp) {  // src/fea/fb.cc:44-54
@@ -274,6 +290,7 @@ Design::Design(const Opts &opts) : o(opts) {
             }
             break;
         }
+        case FeaKind::None: break;  // not reached: the signal path returned above
     }
 
     // ---- output row layout (src/io/out.cc:95-113,174-203) and HTK header fields (145-171)

@@ -19,7 +19,7 @@
 
 namespace ctu {
 
-enum class FeaKind { Spec, LogSpec, Dctc, Lpa, Lpc, TrapDct };
+enum class FeaKind { Spec, LogSpec, Dctc, Lpa, Lpc, TrapDct, None };
 
 struct DesignError : std::runtime_error {
     using std::runtime_error::runtime_error;
@@ -35,6 +35,8 @@ struct Design {
     int post_order = 0;        // number of chained deltaFEA stages (0 = none; -fea_trap: 1)
     bool post_stack = false;   // -fea_trap: the single stage stacks 2*d_win+1 frames instead of differentiating
     int post_w[3] = {0, 0, 0}; // window half-width of each stage (d_win, a_win, t_win)
+    bool signal_out = false;   // -format_out raw|wave: IN -> NR -> sigOUT, no FB / FEA (src/io/batch.cc:62-65)
+    double ola_corr = 1.0;     // largest sum of overlapping Hamming windows (src/io/out.cc:355-377)
     int cms = 0;               // cepstral mean subtraction after the chain: 0 off, 1 exponential, 2 block (src/fea/post_impl.cc:159-240)
     int cms_cols = 0;          // leading row columns it touches (c1..cN and, with -fea_c0, c0)
     int htk_kind = 0;  // HTK parameter kind incl. qualifier bits

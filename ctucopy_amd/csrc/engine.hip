@@ -82,6 +82,7 @@ struct KParams {
     int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
     float nr_p, nr_a;
     unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
+    int skip_phase2;  // signal output (row N3): spectra are exported, nothing is projected
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
 
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // ================= phase 2 (wave-local): lane = (frame, band group) =================
         // The wave's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
         // 8 bands of a slot have similar widths; every group walks the same number of 4-bin chunks per slot.
-        if (p.dbg != 1 && nv > 0) {
+        if (p.dbg != 1 && !p.skip_phase2 && nv > 0) {
             const int f8 = lane >> 3, g = lane & 7;
             const int fslot = wave * 8 + f8;
             const bool fvalid = f8 < nv;
@@ -1454,6 +1455,139 @@ __global__ __launch_bounds__(256) void cmvn_apply_kernel(float *__restrict__ row
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row N3: sigOUT (src/io/out.cc:346-451) - enhanced speech from the post-NR magnitudes and the ORIGINAL phases.
+//   synth_kernel   one wave per frame: X[k] = |Y[k]|/N * X0[k]/|X0[k]| (DC and Nyquist as positive reals, as the
+//                  reference stores them before its sign fix-up, out.cc:416-419), Hermitian -> real by the packed
+//                  half-size inverse FFT  Z[k] = (X[k] + X*[M-k]) + i e^{+2 pi i k/N} (X[k] - X*[M-k]),  z = IDFT_M(Z),
+//                  y[2n] = Re z[n], y[2n+1] = Im z[n]  (radix-4 Stockham passes in LDS, a radix-2 tail when M = 128);
+//                  the first `window` samples of y go to a per-frame scratch row.
+//   ola_kernel     one thread per output sample: sum of the frames that cover it, in frame order as the ring of the
+//                  reference accumulates them, floor(x / correction), +-32767 clip (out.cc:436-451); an utterance of
+//                  T frames yields T*wshift + (window - wshift) samples (the tail is what close() writes).
+// HBM-bound through the spectra scratch (12 B/bin in, 4 B/sample out); fusing the inverse transform into the front
+// end is the obvious next step once this path matters.
+struct SynthParams {
+    int K, wfft, window, wshift;
+    float inv_n;
+    double corr;
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
+                                                    float *__restrict__ ybuf, long long total_frames, const SynthParams sp) {
+    __shared__ float2 root[512];          // e^{+2 pi i m / 512}
+    __shared__ float2 bufs[4][2][260];
+    for (int m = threadIdx.x; m < 512; m += 256) {
+        float sn, cs;
+        sincospif((float)m / 256.0f, &sn, &cs);
+        root[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M = sp.wfft / 2;            // 256 or 128
+    const int rs = 512 / sp.wfft;         // stride of the N-th roots in the table
+    float2 *A = bufs[wave][0], *Bf = bufs[wave][1];
+    for (long long f = (long long)blockIdx.x * 4 + wave; f < total_frames; f += (long long)gridDim.x * 4) {
+        const float2 *xr = xri + f * sp.K;
+        const float *pn = pnr + f * sp.K;
+        for (int k = lane; k <= M; k += 64) {
+            float2 v;
+            if (k == 0 || k == M) v = make_float2(pn[k] * sp.inv_n, 0.f);
+            else {
+                const float2 x0 = xr[k];
+                const float mag2 = x0.x * x0.x + x0.y * x0.y;
+                const float sc = mag2 > 0.f ? pn[k] * sp.inv_n * rsqrtf(mag2) : 0.f;
+                v = make_float2(x0.x * sc, x0.y * sc);
+            }
+            A[k] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = lane; k < M; k += 64) {
+            const float2 a = A[k], b = A[M - k];
+            const float2 sm = make_float2(a.x + b.x, a.y - b.y);      // X[k] + conj(X[M-k])
+            const float2 df = make_float2(a.x - b.x, a.y + b.y);      // X[k] - conj(X[M-k])
+            const float2 w = root[k * rs];
+            // i * w * df
+            const float2 t = make_float2(-(w.x * df.y + w.y * df.x), w.x * df.x - w.y * df.y);
+            Bf[k] = make_float2(sm.x + t.x, sm.y + t.y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float2 *src = Bf, *dst = A;
+        int Ns = 1;
+        const int mr = 512 / M;  // stride of the M-th roots in the table
+        while (Ns * 4 <= M) {
+            const int q4 = M / 4;
+            for (int j = lane; j < q4; j += 64) {
+                const int kk = j % Ns;
+                const int tstep = kk * (M / (4 * Ns)) * mr;  // index of e^{2 pi i kk / (4 Ns)} in the table
+                const float2 v0 = src[j];
+                float2 v1 = src[j + q4], v2 = src[j + 2 * q4], v3 = src[j + 3 * q4];
+                v1 = cmul(v1, root[(tstep) & 511]);
+                v2 = cmul(v2, root[(2 * tstep) & 511]);
+                v3 = cmul(v3, root[(3 * tstep) & 511]);
+                // inverse radix-4 butterfly (W4 = +i)
+                const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+                const int base = (j / Ns) * Ns * 4 + kk;
+                dst[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+                dst[base + Ns] = make_float2(d02.x - d13.y, d02.y + d13.x);      // d02 + i d13
+                dst[base + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+                dst[base + 3 * Ns] = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float2 *tmp = src; src = dst; dst = tmp;
+            Ns *= 4;
+        }
+        if (Ns < M) {  // one radix-2 pass (M = 128)
+            const int h = M / 2;
+            for (int j = lane; j < h; j += 64) {
+                const int kk = j % Ns;
+                const float2 v0 = src[j];
+                const float2 v1 = cmul(src[j + h], root[(kk * (M / (2 * Ns)) * mr) & 511]);
+                const int base = (j / Ns) * Ns * 2 + kk;
+                dst[base] = make_float2(v0.x + v1.x, v0.y + v1.y);
+                dst[base + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float2 *tmp = src; src = dst; dst = tmp;
+        }
+        float2 *yo = reinterpret_cast<float2 *>(ybuf + f * sp.window);  // window is even (checked on the host)
+        for (int n = lane; 2 * n < sp.window; n += 64) yo[n] = src[n];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void ola_kernel(const float *__restrict__ ybuf, int16_t *__restrict__ out,
+                                                  const int4 *__restrict__ utt_info, const long long *__restrict__ sample_off,
+                                                  int n_utt, const SynthParams sp) {
+    const int u = blockIdx.y;
+    if (u >= n_utt) return;
+    const int4 ui = utt_info[u];
+    const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
+    const int T = ui.z, w = sp.window, s = sp.wshift;
+    const long long nout = (long long)T * s + (w - s);
+    int16_t *o = out + sample_off[u];
+    for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < nout; n += (long long)gridDim.x * 256) {
+        long long t0 = (n - w + s) / s;   // ceil((n - w + 1) / s) for n - w + 1 > 0
+        if (n - w + 1 <= 0) t0 = 0;
+        long long t1 = n / s;
+        if (t1 > T - 1) t1 = T - 1;
+        double acc = 0.0;
+        for (long long t = t0; t <= t1; t++) acc += (double)ybuf[(ro + t) * w + (n - t * s)];
+        const int value = (int)floor(acc / sp.corr);
+        o[n] = fabsf((float)value) > 32767.f ? (value < 0 ? -32767 : 32767) : (int16_t)value;
+    }
+}
+
 struct ctu_engine {
     std::unique_ptr<ctu::Design> design;
     int device = 0;
@@ -1469,6 +1603,8 @@ struct ctu_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
+    DevBuf<float> ybuf;       // signal output (row N3): time-domain frames ahead of the overlap-add, sized by the largest plan
+    bool in_signal_call = false;
     DevBuf<float> base_rows;  // front-end rows ahead of the delta / stacking pass, sized by the largest plan seen
     // CMVN (row N2): statistic slot <-> row column maps, and per-call scratch
     std::vector<int> col_of_slot, slot_of_col;
@@ -1492,6 +1628,8 @@ struct ctu_plan {
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
     DevBuf<int64_t> d_row_off;
+    std::vector<int64_t> out_samples;   // signal output: samples written per utterance
+    DevBuf<long long> d_sample_off;
     // TRAP
     DevBuf<int4> utt_info;
     DevBuf<int> trap_chunks;
@@ -1505,6 +1643,20 @@ void set_error(ctu_engine *e, const std::string &m) { e->err = m; }
 // reasons a valid ctucopy configuration is outside the accelerated path
 std::string unsupported_reason(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
+    if (d.signal_out) {  // row N3: IN -> NR -> sigOUT
+        if (o.format_in == "htk") return "HTK feature input with signal output";
+        if (o.fea_kind == "td-iir-mfcc") return "fea_kind outside the spectral path";
+        if (o.dither != 0.) return "-dither != 0 makes outputs depend on file order (src/io/in.cc:205,454)";
+        if (o.remove_dc1) return "-remove_dc1 mutates the sample history across frames (src/io/in.cc:343-350)";
+        if (o.nr_mode != "none" && o.nr_mode != "exten") return "nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221)";
+        if (o.rasta) return "-nr_rasta";
+        if (o.do_vad()) return "VAD together with signal output";
+        if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
+        if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
+        if (d.window % 2) return "odd window length with signal output";
+        if (d.window < 32) return "window shorter than 32 samples";
+        return "";
+    }
     if (o.format_in == "htk") return "HTK feature input (-format_in htk) bypasses the spectral path";
     if (o.fea_kind == "td-iir-mfcc" || o.fea_kind == "none") return "fea_kind outside the spectral feature path";
     if (o.dither != 0.) return "-dither != 0 makes outputs depend on file order (src/io/in.cc:205,454)";
@@ -1770,6 +1922,15 @@ void build_tables(ctu_engine *e) {
         }
     }
     e->lanec.upload(lc);
+    if (d.signal_out) {  // nothing is projected: empty table area
+        e->ncoef_out = 0; e->ck_off = 0; e->cf_off = 0; e->tab_floats = 0; e->NS = 0; e->CW = 16; e->lift_off = 0;
+        e->ftab.upload(std::vector<float>(4, 0.f));
+        e->itab.upload(std::vector<int>(4, 0));
+        e->lds_bytes = ((size_t)TILE * PSTRIDE + LTW_FLOATS) * sizeof(float);
+        e->feat = FEAT_BANDS;
+        e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;
+        return;
+    }
     Phase2Tables t;
     build_phase2(d, t);
     if (check_phase2(d, t) != 0.0) throw std::runtime_error("internal: phase-2 chunk tables do not reproduce the filter bank");
@@ -1795,6 +1956,7 @@ void build_tables(ctu_engine *e) {
         case ctu::FeaKind::Dctc: e->feat = FEAT_DCTC; break;
         case ctu::FeaKind::Lpc:
         case ctu::FeaKind::Lpa: e->feat = FEAT_LP; break;
+        case ctu::FeaKind::None: e->feat = FEAT_BANDS; break;  // not reached: the signal path returns above
     }
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
 }
@@ -1845,6 +2007,7 @@ void fill_dims(const ctu::Design &d, ctu_dims *out) {
     out->has_vad = d.o.do_vad() ? 1 : 0;
     out->swap_out = d.o.swap_out ? 1 : 0;
     out->pcm_align = PCM_ALIGN;
+    out->signal_out = d.signal_out ? 1 : 0;
 }
 
 }  // namespace
@@ -2088,6 +2251,16 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
                 pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
+        if (d.signal_out) {
+            pl->xri.alloc((size_t)ro * d.K);
+            pl->pnr.alloc((size_t)ro * d.K);
+            pl->utt_info.upload(uinfo);
+            std::vector<long long> so64(pl->sample_off.begin(), pl->sample_off.end());
+            pl->d_sample_off.upload(so64);
+            pl->out_samples.resize(n_utt);
+            for (int i = 0; i < n_utt; i++) pl->out_samples[i] = pl->frames[i] * d.wshift + (d.window - d.wshift);
+            if (e->ybuf.n < (size_t)ro * d.window) e->ybuf.alloc((size_t)ro * d.window);
+        }
         if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0 || d.cms || d.o.stat_cmvn || d.o.apply_cmvn) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
@@ -2112,11 +2285,16 @@ int64_t ctu_plan_total_frames(const ctu_plan *p) { return p->total_frames; }
 int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, float *d_rows, uint8_t *d_vad, void *stream) {
     if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
     if (pl->n_tiles == 0) return CTU_OK;
-    if (!d_pcm || !d_rows || (e->do_vad && !d_vad)) {
+    const ctu::Design &d = *e->design;
+    const bool signal = d.signal_out;
+    if (signal && !e->in_signal_call) {
+        set_error(e, "ENGINE: this configuration writes speech (-format_out raw|wave): use ctu_engine_run_signal");
+        return CTU_ERR_INPUT;
+    }
+    if (!d_pcm || (!signal && !d_rows) || (e->do_vad && !d_vad)) {
         set_error(e, "ENGINE: null device buffer");
         return CTU_ERR_INPUT;
     }
-    const ctu::Design &d = *e->design;
     hipStream_t s = (hipStream_t)stream;
     try {
         HIP_TRY(hipSetDevice(e->device));
@@ -2130,7 +2308,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.band_log = d.kind != ctu::FeaKind::Spec;
         kp.band_to_scratch = d.kind == ctu::FeaKind::TrapDct;
         kp.lp_is_lpa = d.kind == ctu::FeaKind::Lpa;
-        kp.vad_export = !e->do_vad ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0));
+        kp.vad_export = signal ? 1 : (!e->do_vad ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0)));
+        kp.skip_phase2 = signal ? 1 : 0;
         kp.tiles = pl->tiles.p;
         kp.wg_first = pl->wg_first.p;
         kp.lanec = e->lanec.p;
@@ -2152,6 +2331,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) kp.e_mode = 2;
             else kp.e_mode = 3;
         }
+        if (signal) kp.e_mode = 0;
         kp.wshift = d.wshift;
         kp.B = d.B;
         kp.nfea = d.nfea;
@@ -2416,6 +2596,69 @@ int ctu_cmvn_apply(ctu_engine *e, const ctu_plan *pl, float *d_rows, const int32
         return CTU_ERR_DEVICE;
     }
     return CTU_OK;
+}
+
+const int64_t *ctu_plan_out_samples(const ctu_plan *p) { return p->out_samples.empty() ? nullptr : p->out_samples.data(); }
+
+int ctu_engine_run_signal(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, int16_t *d_out, void *stream) {
+    if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
+    const ctu::Design &d = *e->design;
+    if (!d.signal_out) {
+        set_error(e, "ENGINE: ctu_engine_run_signal needs -format_out raw|wave");
+        return CTU_ERR_INPUT;
+    }
+    if (pl->n_utt == 0) return CTU_OK;
+    if (!d_pcm || !d_out) {
+        set_error(e, "ENGINE: null device buffer");
+        return CTU_ERR_INPUT;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    e->in_signal_call = true;
+    const int rc = ctu_engine_run(e, pl, d_pcm, nullptr, nullptr, stream);  // spectra before / after NR into the plan's scratch
+    e->in_signal_call = false;
+    if (rc != CTU_OK) return rc;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        SynthParams sp;
+        sp.K = d.K; sp.wfft = d.wfft; sp.window = d.window; sp.wshift = d.wshift;
+        sp.inv_n = 1.0f / (float)d.wfft;
+        sp.corr = d.ola_corr;
+        if (pl->total_frames > 0) {
+            const int g = (int)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 8);
+            hipLaunchKernelGGL(synth_kernel, dim3(g), dim3(256), 0, s, pl->xri.p, pl->pnr.p, e->ybuf.p, (long long)pl->total_frames, sp);
+            HIP_TRY(hipGetLastError());
+        }
+        int64_t longest = 0;
+        for (int64_t n : pl->out_samples) longest = std::max(longest, n);
+        const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((longest + 255) / 256, 64));
+        hipLaunchKernelGGL(ola_kernel, dim3(gx, pl->n_utt), dim3(256), 0, s, e->ybuf.p, d_out, pl->utt_info.p, pl->d_sample_off.p,
+                           pl->n_utt, sp);
+        HIP_TRY(hipGetLastError());
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
+    return CTU_OK;
+}
+
+int ctu_engine_run_signal_host(ctu_engine *e, const ctu_plan *pl, const int16_t *h_pcm, int16_t *h_out) {
+    if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        DevBuf<int16_t> pcm, out;
+        pcm.alloc((size_t)pl->total_samples);
+        out.alloc((size_t)pl->total_samples);
+        HIP_TRY(hipMemcpy(pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(out.p, 0, (size_t)pl->total_samples * 2));
+        const int rc = ctu_engine_run_signal(e, pl, pcm.p, out.p, nullptr);
+        if (rc != CTU_OK) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h_out, out.p, (size_t)pl->total_samples * 2, hipMemcpyDeviceToHost));
+        return CTU_OK;
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
 }
 
 int ctu_cmvn_accumulate_host(ctu_engine *e, const ctu_plan *pl, const float *h_rows, const int32_t *spk_of_utt, int32_t n_spk,

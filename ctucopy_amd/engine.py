@@ -23,7 +23,8 @@ class Dims(ctypes.Structure):
     _fields_ = [("fs", ctypes.c_int32), ("window", ctypes.c_int32), ("wshift", ctypes.c_int32),
                 ("wfft", ctypes.c_int32), ("nbins", ctypes.c_int32), ("nbands", ctypes.c_int32),
                 ("row_floats", ctypes.c_int32), ("htk_kind", ctypes.c_int32), ("htk_period", ctypes.c_uint32),
-                ("has_vad", ctypes.c_int32), ("swap_out", ctypes.c_int32), ("pcm_align", ctypes.c_int32)]
+                ("has_vad", ctypes.c_int32), ("swap_out", ctypes.c_int32), ("pcm_align", ctypes.c_int32),
+                ("signal_out", ctypes.c_int32)]
 
 
 # every symbol include/ctu_engine.h declares (checked by tests/test_abi.py)
@@ -31,7 +32,8 @@ EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_l
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
            "ctu_engine_run_host", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
-           "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host"]
+           "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
+           "ctu_engine_run_signal_host"]
 
 _lib = None
 
@@ -77,6 +79,10 @@ def load_library():
     L.ctu_cmvn_accumulate.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.ctu_cmvn_apply.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.ctu_cmvn_accumulate_host.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.ctu_plan_out_samples.restype = ctypes.POINTER(i64)
+    L.ctu_plan_out_samples.argtypes = [vp]
+    L.ctu_engine_run_signal.argtypes = [vp, vp, vp, vp, vp]
+    L.ctu_engine_run_signal_host.argtypes = [vp, vp, vp, vp]
     L.ctu_cmvn_apply_host.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     _lib = L
     return L
@@ -201,6 +207,19 @@ class Engine:
         if want_vad:
             return rows, vad[:plan.total_frames], per
         return rows
+
+    # ---- speech enhancement output (-format_out raw|wave)
+    def enhance(self, utterances):
+        """list of int16 arrays -> list of int16 arrays (frames*wshift + window-wshift samples each)."""
+        L = load_library()
+        plan = self.plan([len(u) for u in utterances])
+        arena = plan.pack(utterances)
+        out = np.zeros(plan.total_samples, dtype=np.int16)
+        self._check(L.ctu_engine_run_signal_host(self._h, plan._h, arena.ctypes.data, out.ctypes.data))
+        n = L.ctu_plan_out_samples(plan._h)
+        res = [out[plan.sample_off[i]:plan.sample_off[i] + n[i]].copy() for i in range(plan.n_utt)]
+        plan.close()
+        return res
 
     # ---- per-speaker CMVN over device-resident rows (include/ctu_engine.h; src/fea/post_impl.cc:51-118)
     def cmvn_cols(self):

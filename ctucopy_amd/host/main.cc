@@ -262,6 +262,54 @@ void run_shard(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> 
     ctu_plan_destroy(plan);
 }
 
+// -format_out raw|wave: one shard through ctu_engine_run_signal_host, samples per utterance back in `out`
+void run_shard_signal(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> &utts, std::vector<std::vector<int16_t>> &out,
+                      std::string &err) {
+    std::vector<int64_t> ns;
+    for (auto *u : utts) ns.push_back((int64_t)u->size());
+    ctu_plan *plan = nullptr;
+    if (ctu_plan_create(eng, ns.data(), (int)ns.size(), &plan) != CTU_OK) {
+        err = ctu_last_error(eng);
+        return;
+    }
+    const int64_t *so = ctu_plan_sample_offsets(plan), *no = ctu_plan_out_samples(plan);
+    std::vector<int16_t> arena((size_t)ctu_plan_total_samples(plan), 0), res(arena.size(), 0);
+    for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena.begin() + so[i]);
+    if (ctu_engine_run_signal_host(eng, plan, arena.data(), res.data()) != CTU_OK) err = ctu_last_error(eng);
+    else
+        for (size_t i = 0; i < utts.size(); i++) out[i].assign(res.begin() + so[i], res.begin() + so[i] + no[i]);
+    ctu_plan_destroy(plan);
+}
+
+// rawOUT::write (src/io/out.cc:493-499): int16 samples, byte-swapped for -endian_out big
+void write_raw(const std::string &path, const std::vector<int16_t> &x, bool big) {
+    std::vector<uint8_t> b;
+    b.reserve(x.size() * 2);
+    for (int16_t v : x) put16(b, (uint16_t)v, big);
+    write_file(path, b, "OUT: Cannot open output stream!");
+}
+
+// waveOUT (src/io/out.cc:517-564): canonical 44-byte RIFF header, sizes patched at close, samples in host order
+void write_wave(const std::string &path, const std::vector<int16_t> &x, int fs) {
+    std::vector<uint8_t> b;
+    b.reserve(44 + x.size() * 2);
+    const uint32_t data = (uint32_t)(2 * x.size());
+    for (char c : std::string("RIFF")) b.push_back((uint8_t)c);
+    put32(b, data + 36, false);
+    for (char c : std::string("WAVEfmt ")) b.push_back((uint8_t)c);
+    put32(b, 16, false);
+    put16(b, 1, false);
+    put16(b, 1, false);
+    put32(b, (uint32_t)fs, false);
+    put32(b, (uint32_t)fs * 2, false);
+    put16(b, 2, false);
+    put16(b, 16, false);
+    for (char c : std::string("data")) b.push_back((uint8_t)c);
+    put32(b, data, false);
+    for (int16_t v : x) put16(b, (uint16_t)v, false);
+    write_file(path, b, "OUT: Cannot open data file!");
+}
+
 int real_main(int argc, char **argv) {
     std::vector<std::string> args;
     int ngpu = 1;
@@ -280,9 +328,9 @@ int real_main(int argc, char **argv) {
         std::fputs(o.usage().c_str(), stdout);
         return 0;
     }
-    if (o.format_out != "htk" && o.format_out != "ark" && o.format_out != "pfile")
-        throw Fatal(o.format_out.empty() ? "OUT: Unknown output file format!"
-                                         : "ENGINE: only feature outputs (htk, ark=, pfile=) are on the accelerated path");
+    const bool signal_out = o.format_out == "raw" || o.format_out == "wave";
+    if (!signal_out && o.format_out != "htk" && o.format_out != "ark" && o.format_out != "pfile")
+        throw Fatal("OUT: Unknown output file format!");
     // the work list
     std::vector<Item> items;
     if (o.pipe_in || o.pipe_out) throw Fatal("ENGINE: online (pipe) mode is not supported");
@@ -368,6 +416,31 @@ int real_main(int argc, char **argv) {
             const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
             shard[g].push_back(i);
             load[g] += pcm[i].size();
+        }
+        if (signal_out) {  // speech enhancement: samples instead of rows (src/io/batch.cc:62-65,223-227)
+            std::vector<std::vector<int16_t>> wav(n);
+            std::vector<std::string> errs(ngpu);
+            std::vector<std::thread> th;
+            for (int g = 0; g < ngpu; g++)
+                th.emplace_back([&, g] {
+                    std::vector<const std::vector<int16_t> *> u;
+                    std::vector<std::vector<int16_t>> out(shard[g].size());
+                    for (size_t i : shard[g]) u.push_back(&pcm[i]);
+                    if (!u.empty()) run_shard_signal(gpus[g].eng, u, out, errs[g]);
+                    for (size_t k = 0; k < shard[g].size(); k++) wav[shard[g][k]] = std::move(out[k]);
+                });
+            for (auto &t : th) t.join();
+            for (auto &e : errs)
+                if (!e.empty()) throw Fatal(e);
+            for (size_t i = 0; i < n; i++) {
+                const Item &it = items[pos + i];
+                if (o.verbose) std::fprintf(stderr, "processing: %s - %lld frames.\n", it.fin.c_str(),
+                                            (long long)ctu_num_frames(gpus[0].eng, (int64_t)pcm[i].size()));
+                if (o.format_out == "raw") write_raw(it.fout, wav[i], d.swap_out != 0);
+                else write_wave(it.fout, wav[i], o.fs);
+            }
+            pos = end;
+            continue;
         }
         std::vector<std::vector<float>> rows(n);
         std::vector<std::string> vads(n);

@@ -58,6 +58,7 @@ typedef struct {
     int32_t has_vad;    /* a VAD byte per frame is produced, src/io/batch.cc:34-38 */
     int32_t swap_out;   /* caller must byte-swap on write (-endian_out big), src/io/opts.cc:287 */
     int32_t pcm_align;  /* utterance starts inside the packed PCM arena are multiples of this many samples */
+    int32_t signal_out; /* -format_out raw|wave: the engine writes enhanced speech (ctu_engine_run_signal), no rows */
 } ctu_dims;
 
 /* argv = the ctucopy command line without argv[0] (flags of src/io/opts.cc:644-846, incl. -C <file>).
@@ -127,6 +128,16 @@ int ctu_cmvn_accumulate(ctu_engine *, const ctu_plan *, const float *d_rows, con
  * (src/fea/post_impl.cc:104-118).  mean, var: [n_spk][cols] (host, double).  Asynchronous on `stream`. */
 int ctu_cmvn_apply(ctu_engine *, const ctu_plan *, float *d_rows, const int32_t *spk_of_utt, int32_t n_spk,
                    const double *mean, const double *var, void *stream);
+
+/* ---- speech enhancement output (-format_out raw|wave; e.g. -preset exten) ----------------------------------
+ * Replaces `while(in->get_frame()) { nr->process_frame(); out->save_frame(); }` plus the writer's close() for every
+ * file: src/io/batch.cc:223-227,402-407 with sigOUT::save_frame / fill_cache (src/io/out.cc:405-451) and
+ * rawOUT::close (out.cc:487-491).  d_out is an int16 arena laid out like the PCM arena: utterance i's samples start
+ * at ctu_plan_sample_offsets()[i] and ctu_plan_out_samples()[i] = frames*wshift + window - wshift of them are
+ * written (host byte order; the RIFF header and -endian_out are the caller's).  Asynchronous on `stream`. */
+const int64_t *ctu_plan_out_samples(const ctu_plan *);
+int ctu_engine_run_signal(ctu_engine *, const ctu_plan *, const int16_t *d_pcm, int16_t *d_out, void *stream);
+int ctu_engine_run_signal_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, int16_t *h_out);
 
 /* Host-buffer conveniences (H2D of the rows, the call above, D2H for apply; synchronised on return) for callers
  * that hold the rows in host memory, like the `ctucopy` executable. */

@@ -77,6 +77,9 @@ struct ctuo {
     double *ut_re, *ut_im; /* untangle twiddles exp(-2 pi i k / n), k<=n/4.. */
     /* geometry */
     int nfea, D, htk_kind;
+    int signal_out;     /* -format_out raw|wave: enhanced speech instead of features (sigOUT, out.cc:346-451) */
+    double ola_corr;    /* OLA window-sum maximum (out.cc:355-377) */
+    int16_t *sig_buf;   /* destination of the current ctuo_enhance call */
     int post_order;     /* 0 = none, 1..3 = delta stages chained after FEA (batch.cc:122-130) */
     int post_stack;     /* -fea_trap: one stage that stacks 2*d_win+1 frames (fea_delta.cc:166-176) */
     int Xsize;          /* size of the vector OUT sees: nfea, fea_c*(n_order+1) or fea_c*(2*d_win+1) */
@@ -711,8 +714,9 @@ static int design_all(ctuo_t *c) {
     opts_t *o = &c->o;
     if (o->dither != 0.) { set_err(c, "oracle: -dither != 0 makes outputs depend on file order (src/io/in.cc:205,454); not restated"); return -1; }
     if (o->wfft < 8) { set_err(c, "oracle: window too short"); return -1; }
-    if (!strcmp(o->format_in, "htk") || !strcmp(o->fea_kind, "td-iir-mfcc") || !strcmp(o->fea_kind, "none")) {
-        set_err(c, "oracle: only the spectral feature path (raw PCM in, features out) is restated");
+    c->signal_out = (!strcmp(o->format_out, "raw") || !strcmp(o->format_out, "wave"));
+    if (!strcmp(o->format_in, "htk") || !strcmp(o->fea_kind, "td-iir-mfcc") || (!strcmp(o->fea_kind, "none") && !c->signal_out)) {
+        set_err(c, "oracle: only the spectral paths (raw PCM in; features or enhanced speech out) are restated");
         return -1;
     }
     if (strcmp(o->nr_mode, "none") && strcmp(o->nr_mode, "exten")) {
@@ -746,6 +750,25 @@ static int design_all(ctuo_t *c) {
     {
         double pi = 2. * asin(1.);
         for (int j = 0; j < o->window; j++) c->W[j] = 0.54 - (1 - 0.54) * cos(2 * pi * j / (o->window - 1.));
+    }
+    if (c->signal_out) { /* row N3: IN -> NR -> sigOUT; no FB, no FEA (batch.cc:62-65) */
+        if (strcmp(o->vad_apply_mode, "none") || strcmp(o->vad_out_mode, "none")) { set_err(c, "oracle: VAD together with signal output is not restated"); return -1; }
+        r2hc_plan(c, o->wfft);
+        /* OLA correction, out.cc:355-377: the largest sum of overlapping Hamming windows over all phases of the shift */
+        double pi = 2. * asin(1.), min = 999.;
+        c->ola_corr = 0.;
+        for (int i = 0; i < o->wshift; i++) {
+            int xx = i;
+            double y = 0.;
+            while (xx < o->window) { y += 0.54 - (1 - 0.54) * cos(2 * pi * (double)xx / (o->window - 1.)); xx += o->wshift; }
+            if (y > c->ola_corr) c->ola_corr = y;
+            if (y < min) min = y;
+        }
+        c->B = 0; c->nfea = 0; c->D = 0; c->htk_kind = 0; c->do_vad = 0;
+        c->period = (unsigned)floor(.5 + 10000000. * o->wshift / (double)o->fs);
+        c->last_power = calloc(o->wfftby2, sizeof(double));
+        c->last_fbank = calloc(1, sizeof(double));
+        return 0;
     }
     if (fb_design(c)) return -1;
     r2hc_plan(c, o->wfft);
@@ -1187,12 +1210,29 @@ static int dstage_flush(dstage_t *s) { /* fea_delta.cc:178-206 */
 }
 
 /* ------------------------------------------------------------------ the chain */
+long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, unsigned char *vadout);
+
+long ctuo_out_samples(const ctuo_t *c, long nsamples) { /* T frames leave T*wshift samples, close() adds window-wshift */
+    long T = ctuo_num_frames(c, nsamples);
+    if (T < 0) return -1;
+    return T * c->o.wshift + (c->o.window - c->o.wshift);
+}
+
+long ctuo_enhance(ctuo_t *c, const int16_t *pcm, long nsamples, int16_t *out) {
+    if (!c->signal_out) { set_err(c, "oracle: -format_out raw|wave needed for ctuo_enhance"); return -1; }
+    c->sig_buf = out;
+    long n = ctuo_process(c, pcm, nsamples, NULL, NULL);
+    c->sig_buf = NULL;
+    return n;
+}
+
 long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, unsigned char *vadout) {
     opts_t *o = &c->o;
     const int window = o->window, wshift = o->wshift, wfft = o->wfft, K = o->wfftby2, B = c->B;
     const char *kind = o->fea_kind;
     long T = ctuo_num_frames(c, nsamples);
     if (T < 0) { set_err(c, "IO: Signal shorter than one frame!"); return -1; }
+    if (c->signal_out && !c->sig_buf) { set_err(c, "oracle: this configuration writes speech, use ctuo_enhance"); return -1; }
     const int is_trap = !strcmp(kind, "trapdct");
     const int traplen = o->fea_trapdct_traplen, ndct = o->fea_trapdct_ndct, htrap = (traplen + 1) / 2;
     if (is_trap && T > 0 && T < htrap) {
@@ -1256,6 +1296,14 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     }
     double E_last = -1.; /* E is NOT delayed by the median filter: out reads it through a pointer at save time */
 
+    /* sigOUT state (out.cc:397-403): OLA ring of `window` doubles, `start` = ring position of the frame's first sample */
+    double *ola = NULL, *ytime = NULL, *sw1 = NULL, *sw2 = NULL, *sre = NULL, *sim = NULL;
+    long ola_start = 0, nout = 0;
+    if (c->signal_out) {
+        ola = calloc(window, sizeof(double));
+        ytime = malloc(sizeof(double) * wfft); sw1 = malloc(sizeof(double) * wfft); sw2 = malloc(sizeof(double) * wfft);
+        sre = malloc(sizeof(double) * K); sim = malloc(sizeof(double) * K);
+    }
     double preemtmp = 0.; /* in.cc:274 */
     long nrows = 0, nvad = 0;
     int fail = 0;
@@ -1305,6 +1353,44 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         }
         if (!o->fb_power) for (int i = 0; i < K; i++) Xabs[i] = sqrt(Xabs[i]);
 
+        if (c->signal_out) {
+            /* BATCH::process_frame, batch.cc:223-227: nr->process_frame(); save_frame() -> sigOUT::save_frame */
+            if (!strcmp(o->nr_mode, "exten")) { /* nr.cc:95-140 */
+                double aexp = o->nr_a, p = o->nr_p;
+                for (int i = 0; i < K; i++) {
+                    double H;
+                    if (aexp == 1.0) H = Navg[i] / (Navg[i] + Yavg[i]);
+                    else if (aexp == 2.0) H = Navg[i] / sqrt(Navg[i] * Navg[i] + Yavg[i] * Yavg[i]);
+                    else H = Navg[i] / pow(pow(Navg[i], aexp) + pow(Yavg[i], aexp), 1. / aexp);
+                    double N = H * Xabs[i];
+                    Navg[i] = p * Navg[i] + (1 - p) * N;
+                    if (Xabs[i] > Navg[i]) Yavg[i] = Xabs[i] - Navg[i];
+                    else Yavg[i] = Navg[i] - Xabs[i];
+                    Xabs[i] -= N;
+                }
+            }
+            /* out.cc:405-434.  The ring slots that fall out of the window are cleared, the spectrum goes back to
+             * Re/Im with the ORIGINAL phase and a 1/N factor (DC and Nyquist keep their magnitude as a positive real:
+             * the sign flip at out.cc:419 comes after the value was stored), HC2R, overlap-add of the first `window`
+             * samples, then `wshift` finished samples leave through floor(x / correction) with +-32767 clipping. */
+            for (int i = 0; i < wshift; i++) ola[(ola_start + window - wshift + i) % window] = 0.;
+            if (o->fb_power) for (int i = 0; i < K; i++) Xabs[i] = sqrt(Xabs[i]);
+            sre[0] = Xabs[0] / (double)wfft; sim[0] = 0;
+            sre[K - 1] = Xabs[K - 1] / (double)wfft; sim[K - 1] = 0;
+            for (int i = 1; i < K - 1; i++) {
+                double ampl = Xabs[i] / (double)wfft;
+                sre[i] = ampl * cos(Xph[i]);
+                sim[i] = ampl * sin(Xph[i]);
+            }
+            hc2r(sre, sim, wfft, ytime, sw1, sw2);
+            for (int i = 0; i < window; i++) ola[(ola_start + i) % window] += ytime[i];
+            for (int i = 0; i < wshift; i++) {
+                int value = (int)floor(ola[(ola_start + i) % window] / c->ola_corr);
+                c->sig_buf[nout++] = (fabs((float)value) > 32767) ? (value < 0 ? -32767 : 32767) : (int16_t)value;
+            }
+            ola_start += wshift;
+            continue;
+        }
         /* ---- NR / FB order, batch.cc:205-213 */
         double E_nr = -1.;
         double *nrvec = o->nr_when_afterFB ? Y : Xabs;
@@ -1511,6 +1597,13 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         }
     }
 
+    if (c->signal_out) { /* rawOUT::close / waveOUT::close, out.cc:487-491,539-541: the last window-wshift samples */
+        for (int i = 0; i < window - wshift; i++) {
+            int value = (int)floor(ola[(ola_start + i) % window] / c->ola_corr);
+            c->sig_buf[nout++] = (fabs((float)value) > 32767) ? (value < 0 ? -32767 : 32767) : (int16_t)value;
+        }
+        nrows = nout;
+    }
     if (!fail && is_post && T > 0) {
         /* BATCH::fea_delta (batch.cc:172-192) per frame, then BATCH::flush_fea (batch.cc:251-291).  The writers read
          * E through a pointer, so a row carries the energy of the newest frame fed in, not of the frame it describes. */
@@ -1576,6 +1669,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     free(x); free(fft_in); free(Xre); free(Xim); free(zr); free(zi); free(Xabs); free(Xph); free(Y); free(fvec);
     free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin); free(postbuf); free(postE);
     cms_free(&cms);
+    free(ola); free(ytime); free(sw1); free(sw2); free(sre); free(sim);
     free(RRe); free(rc); free(a); free(aa); free(P);
     free(vs.history); free(vs.ring); free(vs.c0); free(vs.ci); free(hw1); free(hw2); free(tsig); free(hre); free(him);
     return fail ? -1 : nrows;

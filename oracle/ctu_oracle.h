@@ -69,6 +69,11 @@ long ctuo_num_frames(const ctuo_t *, long nsamples);
  * num_frames only with -vad_apply_mode drop), or -1 (message via ctuo_error). */
 long ctuo_process(ctuo_t *, const int16_t *pcm, long nsamples, float *rows, unsigned char *vad);
 
+/* -format_out raw|wave (speech enhancement, src/io/out.cc:346-451): `out` receives ctuo_out_samples(nsamples) int16
+ * samples - what rawOUT / waveOUT write for one file, before byte order and the RIFF header.  Returns their number. */
+long ctuo_out_samples(const ctuo_t *, long nsamples);
+long ctuo_enhance(ctuo_t *, const int16_t *pcm, long nsamples, int16_t *out);
+
 const char *ctuo_error(const ctuo_t *);
 
 /* Introspection used by the host-design tests. */

@@ -44,6 +44,10 @@ def lib():
         L.ctuo_get_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(Dims)]
         L.ctuo_num_frames.restype = ctypes.c_long
         L.ctuo_num_frames.argtypes = [ctypes.c_void_p, ctypes.c_long]
+        L.ctuo_out_samples.restype = ctypes.c_long
+        L.ctuo_out_samples.argtypes = [ctypes.c_void_p, ctypes.c_long]
+        L.ctuo_enhance.restype = ctypes.c_long
+        L.ctuo_enhance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
         L.ctuo_process.restype = ctypes.c_long
         L.ctuo_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
         L.ctuo_error.restype = ctypes.c_char_p
@@ -108,6 +112,19 @@ class Oracle:
         if want_vad:
             return out, vad[:T].copy()
         return out
+
+    def enhance(self, pcm):
+        """-format_out raw|wave: int16 samples of the enhanced utterance (what rawOUT/waveOUT write, host byte order)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        L = lib()
+        n = L.ctuo_out_samples(self._h, pcm.size)
+        if n < 0:
+            raise OracleError("IO: Signal shorter than one frame!")
+        out = np.zeros(max(n, 1), dtype=np.int16)
+        got = L.ctuo_enhance(self._h, pcm.ctypes.data, pcm.size, out.ctypes.data)
+        if got < 0:
+            raise OracleError(L.ctuo_error(self._h).decode())
+        return out[:got].copy()
 
     def hamming(self):
         return np.ctypeslib.as_array(lib().ctuo_hamming(self._h), shape=(self.dims.window,)).copy()

@@ -237,3 +237,31 @@ def test_cmvn_statistics_file_and_three_pass_apply(tmp_path):
     # an existing statistics file is refused (the reference's reader is broken, see main.cc)
     r = run(C1 + ["-apply_cmvn", str(stat2), "-S", str(lst2)])
     assert r.returncode != 0 and "existing CMVN statistics" in r.stderr
+
+
+@pytest.mark.gpu
+def test_enhancement_raw_and_wave_files(tmp_path):
+    # the shipped example egs/conf/21_exten.ctuconf: -fs 16000 -format_in raw -format_out raw -preset exten
+    cfg = "-fs 16000 -format_in raw -format_out raw -preset exten".split()
+    lst = _list(tmp_path, ["CS0", "CS3"])
+    r = run(cfg + ["-S", lst, "-v"])
+    assert r.returncode == 0, r.stderr
+    orc = Oracle(cfg)
+    for name in ("CS0", "CS3"):
+        ref = orc.enhance(sig(name))
+        got = np.frombuffer((tmp_path / (name + ".out")).read_bytes(), dtype="<i2")
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert got.shape == ref.shape and d.max() <= 2 and d.mean() < 0.3
+    # WAVE container and big-endian raw
+    r = run([a if a != "raw" or i < 4 else "wave" for i, a in enumerate(cfg)] + ["-S", lst])
+    assert r.returncode == 0, r.stderr
+    img = (tmp_path / "CS3.out").read_bytes()
+    n = len(orc.enhance(sig("CS3")))
+    assert img[:4] == b"RIFF" and img[8:16] == b"WAVEfmt " and img[36:40] == b"data"
+    assert struct.unpack("<I", img[4:8])[0] == 2 * n + 36 and struct.unpack("<I", img[40:44])[0] == 2 * n
+    assert struct.unpack("<IHHIIHH", img[16:36]) == (16, 1, 1, 16000, 32000, 2, 16)
+    wav = np.frombuffer(img[44:], dtype="<i2")
+    r = run(cfg + ["-endian_out", "big", "-S", lst])
+    assert r.returncode == 0, r.stderr
+    be = np.frombuffer((tmp_path / "CS3.out").read_bytes(), dtype=">i2")
+    assert np.array_equal(wav, be.astype(np.int16))

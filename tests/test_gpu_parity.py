@@ -324,3 +324,45 @@ def test_cmvn_argument_checks(Engine):
     plan = eng.plan([16000])
     with pytest.raises(CtuError, match="out of range"):
         eng.cmvn_accumulate(plan, rows, [3], 2)
+
+
+# ---- row N3: speech enhancement output (src/io/out.cc:346-451)
+SIG = "-fs 16000 -format_in raw -format_out raw".split()
+
+
+def _enh_utts():
+    return [sig("CS0"), sig("CS3"), synth_utt(71, 512), synth_utt(72, 300), synth_utt(73, 16000 * 3 + 77), synth_utt(74, 256 * 65 + 256)]
+
+
+@pytest.mark.parametrize("extra,max_lsb,mean_lsb", [
+    (["-nr_mode", "none", "-fea_kind", "none", "-fb_definition", "none", "-w", "32", "-s", "16"], 1, 0.05),
+    (["-nr_mode", "none", "-fea_kind", "none", "-fb_definition", "none", "-w", "25", "-s", "10", "-preem", "0.97"], 1, 0.05),
+    (["-nr_mode", "none", "-fea_kind", "none", "-fb_definition", "none", "-w", "32", "-s", "8", "-remove_dc", "off"], 1, 0.05),
+    (["-preset", "exten"], 2, 0.3),                       # egs/conf/21_exten.ctuconf
+    (["-preset", "exten", "-nr_a", "1", "-nr_p", "0.9"], 2, 0.3),
+])
+def test_enhancement_output(Engine, extra, max_lsb, mean_lsb):
+    # int16 samples come from floor(x / correction): a float32 synthesis can only agree to the last bit where x is
+    # not within its rounding error of an integer, so parity is stated in LSBs (1 LSB = 3e-5 of full scale)
+    cfg = SIG + extra
+    eng, orc = Engine(cfg), Oracle(cfg)
+    assert eng.dims.signal_out == 1
+    utts = [u for u in _enh_utts() if len(u) >= eng.dims.window - eng.dims.wshift]  # shorter ones abort the reference
+    got = eng.enhance(utts)
+    for u, g in zip(utts, got):
+        ref = orc.enhance(u)
+        assert g.shape == ref.shape and g.dtype == np.int16
+        d = np.abs(g.astype(int) - ref.astype(int))
+        assert d.max() <= max_lsb, d.max()
+        assert d.mean() <= mean_lsb, d.mean()
+
+
+def test_enhancement_8khz_and_api_guards(Engine):
+    from ctucopy_amd import CtuError
+    cfg = "-fs 8000 -format_in raw -format_out raw -preset exten".split()  # 256-point transform, two frames per FFT
+    x = sig("CS3")[::2].copy()
+    g, ref = Engine(cfg).enhance([x])[0], Oracle(cfg).enhance(x)
+    d = np.abs(g.astype(int) - ref.astype(int))
+    assert g.shape == ref.shape and d.max() <= 2 and d.mean() < 0.3
+    with pytest.raises(CtuError, match="ctu_engine_run_signal"):
+        Engine(SIG + ["-preset", "exten"]).extract([sig("CS0")])
