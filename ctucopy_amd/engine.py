@@ -221,6 +221,16 @@ class Engine:
         plan.close()
         return res
 
+    def enhance_device(self, plan, pcm, out=None, stream=None):
+        """pcm: torch int16 CUDA tensor [plan.total_samples] -> int16 CUDA tensor of the same layout (async)."""
+        import torch
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.numel() >= plan.total_samples
+        if out is None:
+            out = torch.zeros(plan.total_samples, dtype=torch.int16, device=pcm.device)
+        s = stream if stream is not None else torch.cuda.current_stream(pcm.device)
+        self._check(load_library().ctu_engine_run_signal(self._h, plan._h, pcm.data_ptr(), out.data_ptr(), s.cuda_stream))
+        return out
+
     # ---- per-speaker CMVN over device-resident rows (include/ctu_engine.h; src/fea/post_impl.cc:51-118)
     def cmvn_cols(self):
         return int(load_library().ctu_cmvn_cols(self._h))

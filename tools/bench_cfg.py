@@ -10,7 +10,8 @@ from tests.util import C2, C3, C4, C4_NOVAD, C5
 
 CFGS = {"C2": C2, "C3": C3, "C4": C4, "C4_novad": C4_NOVAD, "C5": C5, "C2_d_a": C2 + ["-fea_delta", "d_a"],
         "C2_trap9": C2 + ["-fea_trap", "9"], "C2_cms_exp": C2 + ["-fea_Z_exp", "2000"], "C2_cms_block": C2 + ["-fea_Z_block", "2000"],
-        "C2_d_a_cms": C2 + ["-fea_delta", "d_a", "-fea_Z_block", "2000"]}
+        "C2_d_a_cms": C2 + ["-fea_delta", "d_a", "-fea_Z_block", "2000"],
+        "exten_raw": "-fs 16000 -format_in raw -format_out raw -preset exten".split()}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="C3")
 ap.add_argument("--utts", type=int, default=2000)
@@ -23,6 +24,19 @@ lens = shard.utterance_lengths(a.utts, 7, lo=3 * fs, hi=15 * fs)
 plan = eng.plan(lens)
 dev = torch.device("cuda", 0)
 pcm = synth_arena(plan.total_samples, 1, dev)
+if eng.dims.signal_out:
+    out = torch.zeros(plan.total_samples, dtype=torch.int16, device=dev)
+    for _ in range(2):
+        eng.enhance_device(plan, pcm, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.enhance_device(plan, pcm, out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"cfg": a.cfg, "frames": plan.total_frames, "ms_per_step": dt * 1e3, "frames_per_s": plan.total_frames / dt,
+                      "front_kernel_ms": eng.last_kernel_ms(), "samples_per_s": plan.total_samples / dt}))
+    sys.exit(0)
 rows = torch.empty((plan.total_frames, eng.dims.row_floats), dtype=torch.float32, device=dev)
 vad = torch.empty(plan.total_frames, dtype=torch.uint8, device=dev) if eng.dims.has_vad else None
 for _ in range(2):
