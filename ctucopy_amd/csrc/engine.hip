@@ -1602,10 +1602,7 @@ struct ctu_engine {
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf<float> logmel;  // TRAP scratch, sized by the largest plan seen
-    DevBuf<float> ybuf;       // signal output (row N3): time-domain frames ahead of the overlap-add, sized by the largest plan
     bool in_signal_call = false;
-    DevBuf<float> base_rows;  // front-end rows ahead of the delta / stacking pass, sized by the largest plan seen
     // CMVN (row N2): statistic slot <-> row column maps, and per-call scratch
     std::vector<int> col_of_slot, slot_of_col;
     DevBuf<int> d_col_of_slot, d_slot_of_col, d_spk;
@@ -1628,6 +1625,10 @@ struct ctu_plan {
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
     DevBuf<int64_t> d_row_off;
+    // scratch between the kernels of one run; owned by the plan, so plans can run concurrently on different streams
+    DevBuf<float> logmel;      // TRAP: log-mel rows [total_frames][B]
+    DevBuf<float> base_rows;   // front-end rows ahead of the delta / stacking / CMS passes [total_frames][Dbase]
+    DevBuf<float> ybuf;        // signal output: time-domain frames ahead of the overlap-add [total_frames][window]
     std::vector<int64_t> out_samples;   // signal output: samples written per utterance
     DevBuf<long long> d_sample_off;
     // TRAP
@@ -2259,15 +2260,15 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             pl->d_sample_off.upload(so64);
             pl->out_samples.resize(n_utt);
             for (int i = 0; i < n_utt; i++) pl->out_samples[i] = pl->frames[i] * d.wshift + (d.window - d.wshift);
-            if (e->ybuf.n < (size_t)ro * d.window) e->ybuf.alloc((size_t)ro * d.window);
+            pl->ybuf.alloc((size_t)ro * d.window);
         }
         if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0 || d.cms || d.o.stat_cmvn || d.o.apply_cmvn) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
             pl->n_trap_chunks = (int)chunks.size() / 2;
         }
-        if (d.kind == ctu::FeaKind::TrapDct && e->logmel.n < (size_t)ro * d.B) e->logmel.alloc((size_t)ro * d.B);
-        if ((d.post_order > 0 || d.cms) && e->base_rows.n < (size_t)ro * d.Dbase) e->base_rows.alloc((size_t)ro * d.Dbase);
+        if (d.kind == ctu::FeaKind::TrapDct) pl->logmel.alloc((size_t)ro * d.B);
+        if (d.post_order > 0 || d.cms) pl->base_rows.alloc((size_t)ro * d.Dbase);
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
@@ -2301,8 +2302,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         KParams kp;
         std::memset(&kp, 0, sizeof kp);
         kp.pcm = d_pcm;
-        kp.rows = (d.post_order > 0 || d.cms) ? e->base_rows.p : d_rows;
-        kp.logmel = e->logmel.p;
+        kp.rows = (d.post_order > 0 || d.cms) ? pl->base_rows.p : d_rows;
+        kp.logmel = pl->logmel.p;
         kp.xri = pl->xri.p;
         kp.pnr = pl->pnr.p;
         kp.band_log = d.kind != ctu::FeaKind::Spec;
@@ -2396,7 +2397,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const int ns = (tl + 3) / 4;
             const size_t shm = (size_t)(64 + 4 * (ns <= 26 ? 26 : ns)) * (d.B | 1) * sizeof(float);
 #define TRAP_LAUNCH(NRB, NSM)                                                                                          \
-    hipLaunchKernelGGL((trapdct_mfma_kernel<NRB, NSM>), dim3(pl->n_trap_chunks), dim3(256), shm, s, e->logmel.p, d_rows, \
+    hipLaunchKernelGGL((trapdct_mfma_kernel<NRB, NSM>), dim3(pl->n_trap_chunks), dim3(256), shm, s, pl->logmel.p, d_rows, \
                        e->trapG.p, pl->utt_info.p, pl->trap_chunks.p, d.B, tl, nd, d.D)
             if (nd <= 16 && ns <= 26) TRAP_LAUNCH(1, 26);
             else if (nd <= 16) TRAP_LAUNCH(1, 64);
@@ -2426,7 +2427,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const size_t shm = ((size_t)R * d.Dbase + (size_t)(d.post_stack ? 0 : d.post_order) * R * pp.fea_c) * sizeof(float);
             if ((size_t)R * d.Dbase > 256 * 12) throw std::runtime_error("delta tile larger than the prefetch registers");
             const int pgrid = std::min(pl->n_trap_chunks, e->n_cu * 8);
-            hipLaunchKernelGGL(post_kernel, dim3(pgrid), dim3(256), shm, s, e->base_rows.p, d_rows,
+            hipLaunchKernelGGL(post_kernel, dim3(pgrid), dim3(256), shm, s, pl->base_rows.p, d_rows,
                                pl->utt_info.p, pl->trap_chunks.p, pl->n_trap_chunks, pp);
             HIP_TRY(hipGetLastError());
         }
@@ -2441,11 +2442,11 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             cp.z = d.o.fea_Z_exp;
             cp.omz = 1 - d.o.fea_Z_exp;
             if (d.cms == 1)
-                hipLaunchKernelGGL(cms_exp_kernel, dim3((pl->n_utt + 1) / 2), dim3(64), 0, s, e->base_rows.p, d_rows,
+                hipLaunchKernelGGL(cms_exp_kernel, dim3((pl->n_utt + 1) / 2), dim3(64), 0, s, pl->base_rows.p, d_rows,
                                    pl->utt_info.p, pl->n_utt, cp);
             else
                 hipLaunchKernelGGL(cms_block_kernel, dim3(pl->n_trap_chunks), dim3(256),
-                                   (size_t)(64 + cp.L - 1) * cp.ncols * sizeof(float), s, e->base_rows.p, d_rows,
+                                   (size_t)(64 + cp.L - 1) * cp.ncols * sizeof(float), s, pl->base_rows.p, d_rows,
                                    pl->utt_info.p, pl->trap_chunks.p, cp);
             HIP_TRY(hipGetLastError());
         }
@@ -2625,13 +2626,13 @@ int ctu_engine_run_signal(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pc
         sp.corr = d.ola_corr;
         if (pl->total_frames > 0) {
             const int g = (int)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 8);
-            hipLaunchKernelGGL(synth_kernel, dim3(g), dim3(256), 0, s, pl->xri.p, pl->pnr.p, e->ybuf.p, (long long)pl->total_frames, sp);
+            hipLaunchKernelGGL(synth_kernel, dim3(g), dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->ybuf.p, (long long)pl->total_frames, sp);
             HIP_TRY(hipGetLastError());
         }
         int64_t longest = 0;
         for (int64_t n : pl->out_samples) longest = std::max(longest, n);
         const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((longest + 255) / 256, 64));
-        hipLaunchKernelGGL(ola_kernel, dim3(gx, pl->n_utt), dim3(256), 0, s, e->ybuf.p, d_out, pl->utt_info.p, pl->d_sample_off.p,
+        hipLaunchKernelGGL(ola_kernel, dim3(gx, pl->n_utt), dim3(256), 0, s, pl->ybuf.p, d_out, pl->utt_info.p, pl->d_sample_off.p,
                            pl->n_utt, sp);
         HIP_TRY(hipGetLastError());
     } catch (const std::exception &ex) {
