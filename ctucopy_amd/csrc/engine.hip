@@ -814,59 +814,127 @@ __device__ __forceinline__ vreal wave_sum_r(vreal x) {
     return x;
 }
 
-template <int Q>  // samples per lane: window <= 64*Q
+// Row rotation by DPP for 32- and 64-bit values (v_mov_b32_dpp per half), and a wave all-reduce built on it: four
+// rotate-and-add steps inside each row of 16 lanes, then the four row sums through v_readlane.  A shuffle-based
+// butterfly (ds_bpermute) costs an LDS round trip per step; the lattice below runs two reductions per order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_read(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double lane_read(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ vreal wave_sum_fast(vreal x) {
+    x += dpp_mov<0x128>(x);  // row_ror:8
+    x += dpp_mov<0x124>(x);  // row_ror:4
+    x += dpp_mov<0x122>(x);  // row_ror:2
+    x += dpp_mov<0x121>(x);  // row_ror:1
+    return (lane_read(x, 0) + lane_read(x, 16)) + (lane_read(x, 32) + lane_read(x, 48));
+}
+
+struct vreal2 { vreal x, y; };
+__device__ __forceinline__ vreal2 vcmul(vreal2 a, vreal2 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+template <int Q, int NCMAX>  // samples per lane: window <= 64*Q; cepstral coefficients: ncoef <= NCMAX
 __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
                                                        double *__restrict__ ci_out, VadParams vp, int64_t total_frames) {
-    __shared__ vreal hr_s[4][260], hi_s[4][260];
-    __shared__ vreal a_s[4][32], aa_s[4][32], cc_s[4][32];  // lattice coefficients: lane 0 of each wave only
+    __shared__ vreal2 root[512];                 // e^{+2 pi i m / 512}
+    __shared__ vreal2 buf_s[4][2][260];          // per wave: ping-pong buffers of the packed half-size inverse FFT
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = vp.K, n = vp.wfft, W = vp.window, nc = vp.ncoef;
-    const int64_t fr = (int64_t)blockIdx.x * 4 + wave;
-    const bool live = fr < total_frames;
-    vreal *hr = hr_s[wave], *hi = hi_s[wave];
-    if (live)
-        for (int k = lane; k < K; k += 64) {  // halfcomplex input: Xa cos(phi), Xa sin(phi)   (src/vad/vad.cc:227-230)
-            const float2 x = xri[fr * K + k];
-            const vreal xa = pnr[fr * K + k];
-            vreal c = 1.0, s_ = 0.0;  // Xph[0] = 0 (src/io/in.cc:398)
-            if (k > 0) {
-                const vreal mag = (vreal)sqrt((double)x.x * x.x + (double)x.y * x.y);
-                if (mag > 0) {
-                    c = x.x / mag;
-                    s_ = x.y / mag;
-                } else {  // c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193); the last bin is 0 or pi by the sign of re (:399)
-                    c = (k == K - 1) ? 1.0 : 0.0;
-                    s_ = (k == K - 1) ? 0.0 : -1.0;
-                }
-                if (k == K - 1) s_ = 0.0;
+    for (int m = tid; m < 512; m += 256) {
+        double sd, cd;
+        sincospi((double)m / 256.0, &sd, &cd);
+        root[m] = {(vreal)cd, (vreal)sd};
+    }
+    __syncthreads();  // the only workgroup barrier; everything below is wave-local (persistent waves walk the frames)
+    const int M = n / 2, rs = 512 / n, mr = 512 / M;
+    vreal2 *A = buf_s[wave][0], *Bf = buf_s[wave][1];
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int64_t fr = (int64_t)blockIdx.x * 4 + wave; fr < total_frames; fr += (int64_t)gridDim.x * 4) {
+    for (int k = lane; k < K; k += 64) {  // halfcomplex input: Xa cos(phi), Xa sin(phi)   (src/vad/vad.cc:227-230)
+        const float2 x = xri[fr * K + k];
+        const vreal xa = pnr[fr * K + k];
+        vreal c = 1.0, s_ = 0.0;  // Xph[0] = 0 (src/io/in.cc:398)
+        if (k > 0) {
+            // direction of a float spectrum value: float arithmetic (v_rsq + one Newton step) is as exact as its input
+            const float mag2 = x.x * x.x + x.y * x.y;
+            if (mag2 > 0.f) {
+                float inv = __builtin_amdgcn_rsqf(mag2);
+                inv = inv * (1.5f - 0.5f * mag2 * inv * inv);
+                c = (vreal)(x.x * inv);
+                s_ = (vreal)(x.y * inv);
+            } else {  // c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193); the last bin is 0 or pi by the sign of re (:399)
+                c = (k == K - 1) ? 1.0 : 0.0;
+                s_ = (k == K - 1) ? 0.0 : -1.0;
             }
-            hr[k] = xa * c;
-            hi[k] = xa * s_;
+            if (k == K - 1) s_ = 0.0;
         }
-    __syncthreads();  // the only workgroup barrier: this wave's spectrum is in LDS
-    if (!live) return;
-    // FFTW_HC2R, unnormalised: x_j = r0 + 2 sum_{k=1}^{n/2-1} (r_k cos(2 pi jk/n) - i_k sin(2 pi jk/n)) + (-1)^j r_{n/2}
-    // The twiddle exp(i 2 pi j k / n) of sample j advances by a fixed rotation per k: kept in registers (a table in
-    // LDS is read with stride k over the lanes and collides on the banks for every even k).
-    vreal ef[Q], eb[Q], wc[Q], ws[Q], rc_[Q], rs_[Q];
+        A[k] = {xa * c, (k == 0 || k == K - 1) ? (vreal)0.0 : xa * s_};  // FFTW's halfcomplex format has no imaginary DC / Nyquist
+    }
+    wave_sync();
+    // FFTW_HC2R, unnormalised: x_j = sum over the Hermitian extension of X_k e^{+2 pi i jk/n}.  Packed half-size form:
+    // Z[k] = (X[k] + X*[M-k]) + i e^{+2 pi i k/n} (X[k] - X*[M-k]),  z = IDFT_M(Z),  x[2m] = Re z[m], x[2m+1] = Im z[m]
+    for (int k = lane; k < M; k += 64) {
+        const vreal2 xa = A[k], xb = A[M - k];
+        const vreal2 sm = {xa.x + xb.x, xa.y - xb.y}, df = {xa.x - xb.x, xa.y + xb.y};
+        const vreal2 w = root[k * rs];
+        Bf[k] = {sm.x - (w.x * df.y + w.y * df.x), sm.y + (w.x * df.x - w.y * df.y)};
+    }
+    wave_sync();
+    vreal2 *src = Bf, *dst = A;
+    int Ns = 1;
+    while (Ns * 4 <= M) {  // radix-4 Stockham passes
+        const int q4 = M / 4;
+        for (int j = lane; j < q4; j += 64) {
+            const int kk = j % Ns, tstep = kk * (M / (4 * Ns)) * mr;
+            const vreal2 v0 = src[j];
+            const vreal2 v1 = vcmul(src[j + q4], root[tstep & 511]);
+            const vreal2 v2 = vcmul(src[j + 2 * q4], root[(2 * tstep) & 511]);
+            const vreal2 v3 = vcmul(src[j + 3 * q4], root[(3 * tstep) & 511]);
+            const vreal2 s02 = {v0.x + v2.x, v0.y + v2.y}, d02 = {v0.x - v2.x, v0.y - v2.y};
+            const vreal2 s13 = {v1.x + v3.x, v1.y + v3.y}, d13 = {v1.x - v3.x, v1.y - v3.y};
+            const int base = (j / Ns) * Ns * 4 + kk;
+            dst[base] = {s02.x + s13.x, s02.y + s13.y};
+            dst[base + Ns] = {d02.x - d13.y, d02.y + d13.x};
+            dst[base + 2 * Ns] = {s02.x - s13.x, s02.y - s13.y};
+            dst[base + 3 * Ns] = {d02.x + d13.y, d02.y - d13.x};
+        }
+        wave_sync();
+        vreal2 *t_ = src; src = dst; dst = t_;
+        Ns *= 4;
+    }
+    if (Ns < M) {  // radix-2 tail (M = 128)
+        const int h = M / 2;
+        for (int j = lane; j < h; j += 64) {
+            const int kk = j % Ns;
+            const vreal2 v0 = src[j], v1 = vcmul(src[j + h], root[(kk * (M / (2 * Ns)) * mr) & 511]);
+            const int base = (j / Ns) * Ns * 2 + kk;
+            dst[base] = {v0.x + v1.x, v0.y + v1.y};
+            dst[base + Ns] = {v0.x - v1.x, v0.y - v1.y};
+        }
+        wave_sync();
+        vreal2 *t_ = src; src = dst; dst = t_;
+    }
+    vreal ef[Q], eb[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int j = lane + 64 * q;
-        ef[q] = hr[0] + ((j & 1) ? -hr[K - 1] : hr[K - 1]);
-        { double sd, cd; sincos(2.0 * 3.14159265358979323846 * (double)j / (double)n, &sd, &cd); rs_[q] = (vreal)sd; rc_[q] = (vreal)cd; }
-        wc[q] = rc_[q];  // k = 1
-        ws[q] = rs_[q];
+        const vreal2 z = src[(j >> 1) & (M - 1)];
+        ef[q] = (j & 1) ? z.y : z.x;
     }
-    for (int k = 1; k < K - 1; k++) {
-        const vreal rk = 2.0 * hr[k], ik = 2.0 * hi[k];
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            ef[q] += rk * wc[q] - ik * ws[q];
-            const vreal c2 = wc[q] * rc_[q] - ws[q] * rs_[q];
-            ws[q] = ws[q] * rc_[q] + wc[q] * rs_[q];
-            wc[q] = c2;
-        }
-    }
+    wave_sync();  // the buffers are free for the next frame once every lane has its samples
     vreal part = 0.0;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -874,17 +942,17 @@ __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict_
         eb[q] = ef[q];
         part += ef[q] * ef[q];
     }
-    vreal alpha = wave_sum_r(part) / (vreal)W;
-    // Burg lattice (src/vdet/Burg.h:49-95); the coefficient recursion a[] / aa[] is kept by lane 0 in LDS
-    vreal *a = a_s[wave], *aa = aa_s[wave], *cc = cc_s[wave];
-    if (lane == 0) a[0] = 1.0;
+    vreal alpha = wave_sum_fast(part) / (vreal)W;
+    // Burg lattice (src/vdet/Burg.h:49-95).  Prediction coefficients live one per lane (lane i = a[i]); the order
+    // update a'[i] = a[i] + rc a[ik-i] is one cross-lane read.
+    vreal acoef = lane == 0 ? (vreal)1.0 : (vreal)0.0;
     for (int ik = 1; ik < nc; ik++) {
         // eb[i-1]: the previous sample sits in the previous lane (or lane 63 of the previous q)
         vreal ebm[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const vreal up = __shfl_up(eb[q], 1, 64);
-            const vreal wrap = q > 0 ? __shfl(eb[q > 0 ? q - 1 : 0], 63, 64) : 0.0;
+            const vreal up = dpp_mov<0x138>(eb[q]);  // wave_shr:1
+            const vreal wrap = q > 0 ? lane_read(eb[q > 0 ? q - 1 : 0], 63) : (vreal)0.0;
             ebm[q] = lane == 0 ? wrap : up;
         }
         vreal num = 0.0, den = 0.0;
@@ -896,8 +964,8 @@ __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict_
                 num += ef[q] * ebm[q];
             }
         }
-        num = wave_sum_r(num);
-        den = wave_sum_r(den);
+        num = wave_sum_fast(num);
+        den = wave_sum_fast(den);
         const vreal rc = -(2.0 * num) / den;
         alpha *= 1.0 - rc * rc;
 #pragma unroll
@@ -909,21 +977,27 @@ __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict_
                 eb[q] = neb;
             }
         }
-        if (lane == 0) {
-            a[ik] = rc;
-            for (int i = 1; i < ik; i++) a[i] = aa[i] + rc * aa[ik - i];
-            for (int i = 1; i <= ik; i++) aa[i] = a[i];
-        }
+        const vreal other = __shfl(acoef, (ik - lane) & 63, 64);
+        acoef = (lane >= 1 && lane < ik) ? acoef + rc * other : (lane == ik ? rc : acoef);
     }
-    if (lane == 0) {  // Burg2Cepstrum (src/vdet/Burg.h:141-152)
-        for (int m = 1; m < nc; m++) {
-            vreal sum = 0.0;
-            for (int k = 1; k < m; k++) sum += (m - k) * cc[m - k] * a[k];
-            cc[m] = -a[m] - sum / m;
-        }
+    // Burg2Cepstrum (src/vdet/Burg.h:141-152) in registers, the same in every lane; lane m keeps c[m] for the store
+    {
+        vreal av[NCMAX], cc[NCMAX];
+#pragma unroll
+        for (int i = 0; i < NCMAX; i++) av[i] = lane_read(acoef, i);
         cc[0] = (vreal)log((double)alpha);
-        for (int m = 0; m < nc; m++) ci_out[fr * nc + m] = (double)cc[m];
+        vreal mine = cc[0];
+#pragma unroll
+        for (int m = 1; m < NCMAX; m++) {
+            vreal sum = 0.0;
+#pragma unroll
+            for (int k = 1; k < m; k++) sum += (vreal)(m - k) * cc[m - k] * av[k];
+            cc[m] = -av[m] - sum * (vreal)(1.0 / m);
+            mine = lane == m ? cc[m] : mine;
+        }
+        if (lane < nc) ci_out[fr * nc + lane] = (double)mine;
     }
+    }  // frames
 }
 
 // One wave per utterance (src/vad/vad.cc:220-294 distance + background, :329-625 thresholds, vad.h:126-175 filter).
@@ -2382,11 +2456,16 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #endif
         if (e->do_vad) {
             if (e->vp.cri == 1) {
-                const dim3 g((unsigned)((pl->total_frames + 3) / 4));
-                if (d.window <= 256)
-                    hipLaunchKernelGGL(vad_burg_kernel<4>, g, dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames);
-                else
-                    hipLaunchKernelGGL(vad_burg_kernel<8>, g, dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames);
+                const dim3 g((unsigned)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 3));
+#define BURG_LAUNCH(Q, NC) hipLaunchKernelGGL((vad_burg_kernel<Q, NC>), g, dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames)
+                if (d.window <= 256) {
+                    if (e->vp.ncoef <= 16) BURG_LAUNCH(4, 16);
+                    else BURG_LAUNCH(4, 32);
+                } else {
+                    if (e->vp.ncoef <= 16) BURG_LAUNCH(8, 16);
+                    else BURG_LAUNCH(8, 32);
+                }
+#undef BURG_LAUNCH
             }
             hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
                                pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
