@@ -831,7 +831,8 @@ __device__ __forceinline__ float lane_read(float x, int l) { return __int_as_flo
 __device__ __forceinline__ double lane_read(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
-__device__ __forceinline__ vreal wave_sum_fast(vreal x) {
+template <class T>
+__device__ __forceinline__ T wave_sum_fast(T x) {
     x += dpp_mov<0x128>(x);  // row_ror:8
     x += dpp_mov<0x124>(x);  // row_ror:4
     x += dpp_mov<0x122>(x);  // row_ror:2
@@ -845,8 +846,8 @@ __device__ __forceinline__ vreal2 vcmul(vreal2 a, vreal2 b) { return {a.x * b.x 
 template <int Q, int NCMAX>  // samples per lane: window <= 64*Q; cepstral coefficients: ncoef <= NCMAX
 __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
                                                        double *__restrict__ ci_out, VadParams vp, int64_t total_frames) {
-    __shared__ vreal2 root[512];                 // e^{+2 pi i m / 512}
-    __shared__ vreal2 buf_s[4][2][260];          // per wave: ping-pong buffers of the packed half-size inverse FFT
+    extern __shared__ __align__(16) unsigned char burg_lds[];
+    vreal2 *root = reinterpret_cast<vreal2 *>(burg_lds);  // [512] e^{+2 pi i m / 512}; then per wave 2 x [wfft/2 + 4] ping-pong
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = vp.K, n = vp.wfft, W = vp.window, nc = vp.ncoef;
     for (int m = tid; m < 512; m += 256) {
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict_
     }
     __syncthreads();  // the only workgroup barrier; everything below is wave-local (persistent waves walk the frames)
     const int M = n / 2, rs = 512 / n, mr = 512 / M;
-    vreal2 *A = buf_s[wave][0], *Bf = buf_s[wave][1];
+    vreal2 *A = root + 512 + (size_t)wave * 2 * (M + 4), *Bf = A + (M + 4);
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1007,18 +1008,23 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
                                                          const float *__restrict__ rows, const int64_t *__restrict__ row_off,
                                                          int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
     __shared__ double stage[64 * 32];
-    __shared__ double c0[32];
     const int u = blockIdx.x, lane = threadIdx.x;
     if (u >= n_utt) return;
     const int64_t r0 = row_off[u];
     const int T = (int)(row_off[u + 1] - r0);
     const int nc = vp.cri == 0 ? 1 : vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
-    int hist[33];
-#pragma unroll
-    for (int i = 0; i < 33; i++) hist[i] = 0;
+    // majority filter (src/vad/vad.h:126-175): the last `order` (<= 31) raw decisions as bits, with a running count
+    unsigned long long hist = 0;
     int hidx = 0, nout = 0, nsum = 0;
+    auto push = [&](int v) {
+        const int old = (int)((hist >> hidx) & 1ull);
+        hist = (hist & ~(1ull << hidx)) | ((unsigned long long)v << hidx);
+        nsum += v - old;
+        hidx = (hidx + 1 == order) ? 0 : hidx + 1;
+    };
     double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
     int adapt_vad = 0;
+    double c0r = 0.0;  // background cepstrum, coefficient `lane` (src/vad/vad.cc:220-294)
     for (int tb = 0; tb < T; tb += 64) {
         const int nt = min(64, T - tb);
         __syncthreads();
@@ -1036,24 +1042,21 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
         __syncthreads();
         for (int tt = 0; tt < nt; tt++) {
             const int t = tb + tt;
-            const double *ci = stage + tt * nc;
-            double cri;
+            double cri, cil = 0.0;
             if (vp.cri == 0) {
-                double en = ci[0];
+                double en = stage[tt];
                 if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
                 cri = en;
-            } else if (t == 0) {
-                if (lane < nc) c0[lane] = ci[lane];
-                __syncthreads();
-                cri = 0.0;
             } else {
-                if (t == 1) {
-                    if (lane < nc) c0[lane] = (c0[lane] + ci[lane]) / 2.0;
-                    __syncthreads();
+                cil = lane < nc ? stage[tt * nc + lane] : 0.0;
+                if (t == 0) {
+                    c0r = cil;
+                    cri = 0.0;
+                } else {
+                    if (t == 1) c0r = (c0r + cil) / 2.0;
+                    const double dl = (lane >= 1 && lane < nc) ? cil - c0r : 0.0;  // c0 itself is not part of the distance
+                    cri = 4.3429 * sqrt(2 * wave_sum_fast(dl * dl));
                 }
-                double sum = 0.0;
-                for (int i = 1; i < nc; i++) sum += (ci[i] - c0[i]) * (ci[i] - c0[i]);
-                cri = 4.3429 * sqrt(2 * sum);
             }
             int vad0;
             if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
@@ -1096,19 +1099,9 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
                     vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
                 }
             }
-            if (vp.cri != 0 && !(vad0 && t > vp.cep_init)) {  // background update (src/vad/vad.cc:288-294)
-                __syncthreads();
-                if (lane < nc) c0[lane] = vp.cep_p * c0[lane] + (1.0 - vp.cep_p) * ci[lane];
-                __syncthreads();
-            }
-            // majority filter over the last `order` raw decisions (running count instead of re-summing)
-            int old = 0;
-#pragma unroll
-            for (int i = 0; i < 33; i++) old = (i == hidx) ? hist[i] : old;
-#pragma unroll
-            for (int i = 0; i < 33; i++) hist[i] = (i == hidx) ? vad0 : hist[i];
-            nsum += vad0 - old;
-            hidx = (hidx + 1 == order) ? 0 : hidx + 1;
+            if (vp.cri != 0 && !(vad0 && t > vp.cep_init))  // background update (src/vad/vad.cc:288-294)
+                c0r = vp.cep_p * c0r + (1.0 - vp.cep_p) * cil;
+            push(vad0);
             if (t >= h) {
                 if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
                 nout++;
@@ -1116,13 +1109,7 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
         }
     }
     for (int k = 0; k < h && nout < T; k++) {  // flush: zeros pushed (src/vad/vad.h:156-175)
-        int old = 0;
-#pragma unroll
-        for (int i = 0; i < 33; i++) old = (i == hidx) ? hist[i] : old;
-#pragma unroll
-        for (int i = 0; i < 33; i++) hist[i] = (i == hidx) ? 0 : hist[i];
-        nsum -= old;
-        hidx = (hidx + 1 == order) ? 0 : hidx + 1;
+        push(0);
         if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
         nout++;
     }
@@ -2456,8 +2443,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #endif
         if (e->do_vad) {
             if (e->vp.cri == 1) {
-                const dim3 g((unsigned)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 3));
-#define BURG_LAUNCH(Q, NC) hipLaunchKernelGGL((vad_burg_kernel<Q, NC>), g, dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames)
+                const dim3 g((unsigned)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 4));
+                const size_t bshm = (512 + (size_t)4 * 2 * (d.wfft / 2 + 4)) * 2 * sizeof(vreal);
+#define BURG_LAUNCH(Q, NC) hipLaunchKernelGGL((vad_burg_kernel<Q, NC>), g, dim3(256), bshm, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames)
                 if (d.window <= 256) {
                     if (e->vp.ncoef <= 16) BURG_LAUNCH(4, 16);
                     else BURG_LAUNCH(4, 32);
