@@ -163,7 +163,7 @@ struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-
 
 // Phase-2 helpers with a compile-time coefficient count (16 or MAXC) so that nothing branches per coefficient.
 template <int NCW>
-__device__ __forceinline__ void cell_accumulate(float (&c)[MAXC], const float4 *cf, float y) {
+__device__ __forceinline__ void cell_accumulate(float (&c)[NCW], const float4 *cf, float y) {
     float4 k4[NCW / 4];
 #pragma unroll
     for (int i = 0; i < NCW / 4; i++) k4[i] = cf[i];  // all loads first, then the FMAs
@@ -176,7 +176,7 @@ __device__ __forceinline__ void cell_accumulate(float (&c)[MAXC], const float4 *
     }
 }
 template <int NCW>
-__device__ __forceinline__ void cells_reduce(float (&c)[MAXC]) {
+__device__ __forceinline__ void cells_reduce(float (&c)[NCW]) {
 #pragma unroll
     for (int i = 0; i < NCW; i++) c[i] = lanes8_allreduce_add(c[i]);
 }
@@ -232,7 +232,9 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
 // MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
 //         (no twiddles in the untangle), NZ = rows of 16 samples, one pass of 8 frames.
 // VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
-template <int NZ, int FEAT, int MODE, bool VX>
+// NC:     coefficients accumulated per frame in phase 2 (16 or MAXC): a compile-time width keeps eight accumulators
+//         and a code path out of the common instantiation (9 -> 2 spilled VGPRs, +5 %).
+template <int NZ, int FEAT, int MODE, bool VX, int NC>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
@@ -610,9 +612,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             const int fslot = wave * 8 + f8;
             const bool fvalid = f8 < nv;
             const float *prow2 = Pt + fslot * PSTRIDE;
-            float c[MAXC];
+            float c[NC];
 #pragma unroll
-            for (int i = 0; i < MAXC; i++) c[i] = 0.f;
+            for (int i = 0; i < NC; i++) c[i] = 0.f;
             float esum = 0.f;
             if (p.e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
                 const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : wave * 8) * p.wshift;
@@ -679,9 +681,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 } else {
                     if (FEAT == FEAT_LP && !p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
-                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (p.CW + 4));  // +4: bank spread
-                    if (p.CW == 16) cell_accumulate<16>(c, cf, y);
-                    else cell_accumulate<MAXC>(c, cf, y);
+                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
+                    cell_accumulate<NC>(c, cf, y);
                 }
             }
             STAMP(8);  // filter bank + per-band accumulation
@@ -692,14 +693,13 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 if (p.e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
             }
             if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
-                if (p.CW == 16) cells_reduce<16>(c);
-                else cells_reduce<MAXC>(c);
+                cells_reduce<NC>(c);
                 float *orow = p.rows + (rbase + fslot) * p.D;
                 if (FEAT == FEAT_DCTC) {
                     // c[r] = value of output slot r = sum_b dct[i(r)][b] * logY[b]  (norm, lifter and the writer's
                     // c1..cN,c0 order are folded into the table on the host); lane g stores slots g, g+8, g+16
 #pragma unroll
-                    for (int h = 0; h < MAXC / 8; h++) {
+                    for (int h = 0; h < NC / 8; h++) {
                         if (h * 8 < p.ncoef_out) {
                             float val = c[h * 8];
 #pragma unroll
@@ -723,8 +723,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     a[1] = rc;
 #pragma unroll
                     for (int ik = 2; ik <= MAX_LP; ik++) {
-                        if (ik <= P_) {
-                            float dm = c[ik];
+                        if (ik <= P_ && ik < NC) {  // the host picks NC > lporder
+                            float dm = c[ik < NC ? ik : NC - 1];
 #pragma unroll
                             for (int n = 1; n < ik; n++) dm += a[n] * c[ik - n];
                             rc = -dm / err;
@@ -2025,22 +2025,22 @@ void build_tables(ctu_engine *e) {
 
 template <int NZ, int MODE, bool VX>
 void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
-#define LAUNCH(F)                                                                                      \
-    case F: {                                                                                          \
+#define LAUNCH(F, NCW)                                                                                 \
+    {                                                                                                  \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX>), \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX, NCW>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX>), grid, dim3(WG), shm, s, kp);             \
-        break;                                                                                         \
+        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX, NCW>), grid, dim3(WG), shm, s, kp);        \
     }
-    switch (feat) {
-        LAUNCH(FEAT_BANDS)
-        LAUNCH(FEAT_DCTC)
-        LAUNCH(FEAT_LP)
-    }
+    const bool wide = kp.CW != 16;  // coefficient rows of MAXC entries (more than 16 cepstra / LP lags)
+    if (feat == FEAT_BANDS) LAUNCH(FEAT_BANDS, 16)
+    else if (feat == FEAT_DCTC && !wide) LAUNCH(FEAT_DCTC, 16)
+    else if (feat == FEAT_DCTC) LAUNCH(FEAT_DCTC, MAXC)
+    else if (!wide) LAUNCH(FEAT_LP, 16)
+    else LAUNCH(FEAT_LP, MAXC)
 #undef LAUNCH
 }
 
