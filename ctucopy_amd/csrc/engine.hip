@@ -234,8 +234,14 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
 // VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
 // NC:     coefficients accumulated per frame in phase 2 (16 or MAXC): a compile-time width keeps eight accumulators
 //         and a code path out of the common instantiation (9 -> 2 spilled VGPRs, +5 %).
-template <int NZ, int FEAT, int MODE, bool VX, int NC>
+// GEN:    false = the plain chain (DC removal on, power spectrum, no -fea_E, no exten, no intensity-loudness law, no
+//         diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills (+4 %).
+template <int NZ, int FEAT, int MODE, bool VX, int NC, bool GEN>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
+    const int o_e_mode = GEN ? p.e_mode : 0, o_dbg = GEN ? p.dbg : 0;
+    const bool o_fb_inld = GEN ? p.fb_inld != 0 : false, o_nr_exten = GEN ? p.nr_exten != 0 : false;
+    const bool o_fb_power = GEN ? p.fb_power != 0 : true, o_remove_dc = GEN ? p.remove_dc != 0 : true;
+    const bool o_skip_phase2 = GEN ? p.skip_phase2 != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
     float *ltab = lds + TILE * PSTRIDE;    // phase-2 tables (layout: KParams)
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // pass B (slots 4-7) copied by LDS-DMA into the wave's rows 4-7, which nobody needs before pass B
         // writes its spectra there.  The transpose scratch is rows 0-3 in pass A and rows 4-7 in pass B.
         constexpr bool DMA = CTU_LDSDMA && (NZ <= 15) && MODE == 0;  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
-        if (p.dbg != 2 && nv > 0) {
+        if (o_dbg != 2 && nv > 0) {
             const int npass = (MODE == 0 && nv > 4) ? 2 : 1;
             // the pass body is instantiated twice (it = 0, 1) so that the choice of transpose is made at compile time
             auto pass = [&](auto IT) {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 #pragma unroll
                     for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
                     STAMP(1);
-                    if (p.remove_dc) {
+                    if (o_remove_dc) {
                         const float ma = row16_allreduce_add(dca) * p.inv_window, mb = row16_allreduce_add(dcb) * p.inv_window;
 #pragma unroll
                         for (int j = 0; j < NZ; j++) {
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 #pragma unroll
                 for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
                 STAMP(1);  // PCM + window loads, convert, pre-emphasis, window
-                if (p.remove_dc) {
+                if (o_remove_dc) {
                     // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
                     const float m = row16_allreduce_add(dc) * p.inv_window;
                     if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     if (l16 == 0) {
                         pa[128] = v[8].x * v[8].x;
                         pb[128] = v[8].y * v[8].y;
-                        if (p.remove_dc) pa[0] = pb[0] = 1e-10f;
+                        if (o_remove_dc) pa[0] = pb[0] = 1e-10f;
                         if (VX && p.vad_export == 1) {
                             const int fa = wave * 8 + 2 * fg;
                             if (fa < nvalid) p.xri[(rbase + fa) * 129 + 128] = make_float2(v[8].x, 0.f);
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
                 if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
                     prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
-                    if (p.remove_dc) prow[0] = 1e-10f;
+                    if (o_remove_dc) prow[0] = 1e-10f;
                     if (VX && p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
                 }
                 }
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        if (!p.fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
+        if (!o_fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
             for (int e = lane; e < nv * p.K; e += 64) {
                 const int f = e / p.K, k = e - f * p.K;
                 float *q_ = Pt + (wave * 8 + f) * PSTRIDE + k;
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 
         // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
         // The only cross-wave step: one lane per bin walks the tile's frames in order (workgroup barriers).
-        if (p.nr_exten) {
+        if (o_nr_exten) {
             __syncthreads();
             if (rec.t0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
                 navg = 0.95f;
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // ================= phase 2 (wave-local): lane = (frame, band group) =================
         // The wave's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
         // 8 bands of a slot have similar widths; every group walks the same number of 4-bin chunks per slot.
-        if (p.dbg != 1 && !p.skip_phase2 && nv > 0) {
+        if (o_dbg != 1 && !o_skip_phase2 && nv > 0) {
             const int f8 = lane >> 3, g = lane & 7;
             const int fslot = wave * 8 + f8;
             const bool fvalid = f8 < nv;
@@ -616,14 +622,14 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 #pragma unroll
             for (int i = 0; i < NC; i++) c[i] = 0.f;
             float esum = 0.f;
-            if (p.e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
+            if (o_e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
                 const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : wave * 8) * p.wshift;
                 for (int i = 1 + g; i < p.window; i += 8) {
                     const float x = (float)xr[i];
                     esum += x * x;
                 }
             }
-            if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
+            if (o_e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
                 for (int k = g; k < p.K; k += 8) {
                     const float x = prow2[k];
                     esum += ((k == 0 || k == p.K - 1) ? 0.5f : 1.0f) * x * x;
@@ -669,28 +675,28 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
                 acc += acc1;
                 float y = acc;
-                if (p.fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
+                if (o_fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
                 // v_log_f32 (log2, ~1 ulp) * ln 2: band energies of int16 speech are far from the denormal range
                 if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __builtin_amdgcn_logf(y) * 0.69314718056f;
-                if (p.e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
+                if (o_e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
                     esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5f : 1.0f) * acc * acc;
                 if (FEAT == FEAT_BANDS) {
                     float *dst = p.band_to_scratch ? p.logmel : p.rows;
                     const int out_w = p.band_to_scratch ? p.B : p.D;
                     if (bidx >= 0 && fvalid) dst[(rbase + fslot) * out_w + bidx] = y;
                 } else {
-                    if (FEAT == FEAT_LP && !p.fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
+                    if (FEAT == FEAT_LP && !o_fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
                     const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
                     cell_accumulate<NC>(c, cf, y);
                 }
             }
             STAMP(8);  // filter bank + per-band accumulation
-            if (p.e_mode && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
+            if (o_e_mode && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
                 float e = 0.f;
-                if (p.e_mode == 1 || p.e_mode == 3) e = __logf(2.0f * lanes8_allreduce_add(esum));
-                else if (p.e_mode == 4) e = __logf(lanes8_allreduce_add(esum));
-                if (p.e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
+                if (o_e_mode == 1 || o_e_mode == 3) e = __logf(2.0f * lanes8_allreduce_add(esum));
+                else if (o_e_mode == 4) e = __logf(lanes8_allreduce_add(esum));
+                if (o_e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
             }
             if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
                 cells_reduce<NC>(c);
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const int P_ = p.lporder;
                     float a[MAX_LP + 1], cc[MAX_LP + 1];
                     const float r0 = c[0];
-                    if (p.e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = __builtin_amdgcn_logf(r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
+                    if (o_e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = __builtin_amdgcn_logf(r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
                     float rc = -c[1] / r0;
                     float err = r0 * (1 - rc * rc);
                     a[0] = 1;
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             }
             STAMP(10);  // reduction, tail, row store
         }
-        if (p.nr_exten) __syncthreads();  // the bin-wise NR pass of the next tile reads every wave's rows
+        if (o_nr_exten) __syncthreads();  // the bin-wise NR pass of the next tile reads every wave's rows
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (next < 0) break;
@@ -2023,17 +2029,17 @@ void build_tables(ctu_engine *e) {
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
 }
 
-template <int NZ, int MODE, bool VX>
+template <int NZ, int MODE, bool VX, bool GEN>
 void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
 #define LAUNCH(F, NCW)                                                                                 \
     {                                                                                                  \
         static bool attr_set = false;                                                                  \
         if (!attr_set) {                                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX, NCW>), \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX, NCW, GEN>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
             attr_set = true;                                                                           \
         }                                                                                              \
-        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX, NCW>), grid, dim3(WG), shm, s, kp);        \
+        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX, NCW, GEN>), grid, dim3(WG), shm, s, kp);   \
     }
     const bool wide = kp.CW != 16;  // coefficient rows of MAXC entries (more than 16 cepstra / LP lags)
     if (feat == FEAT_BANDS) LAUNCH(FEAT_BANDS, 16)
@@ -2046,8 +2052,11 @@ void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm
 
 template <int NZ, int MODE>
 void launch_vx(bool vx, int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
-    if (vx) launch_nz<NZ, MODE, true>(feat, grid, s, kp, shm);
-    else launch_nz<NZ, MODE, false>(feat, grid, s, kp, shm);
+    // the plain chain gets its own instantiation (see GEN); everything else, and every VAD-export run, is generic
+    const bool plain = !vx && kp.e_mode == 0 && !kp.fb_inld && !kp.nr_exten && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
+    if (vx) launch_nz<NZ, MODE, true, true>(feat, grid, s, kp, shm);
+    else if (plain) launch_nz<NZ, MODE, false, false>(feat, grid, s, kp, shm);
+    else launch_nz<NZ, MODE, false, true>(feat, grid, s, kp, shm);
 }
 
 std::vector<std::string> to_args(int argc, const char *const *argv) {

@@ -170,7 +170,9 @@ def test_vad_drop_mode_row_counts(Engine):
     for r, v, f in zip(rows, vads, full):
         keep = v == ord("1")
         assert r.shape[0] == int(keep.sum())
-        assert rel_err(r, f[keep]) <= 1e-5   # two instantiations of the kernel (with / without the VAD export)
+        # two instantiations of the kernel (generic with the VAD export / plain): the compiler contracts and orders the
+        # float operations differently, so they agree to the fp32 noise floor of the chain, like either does with the oracle
+        assert rel_err(r, f[keep]) <= TOL
 
 
 def test_c5_trapdct(Engine):
