@@ -11,7 +11,8 @@ from tests.util import C2, C3, C4, C4_NOVAD, C5
 CFGS = {"C2": C2, "C3": C3, "C4": C4, "C4_novad": C4_NOVAD, "C5": C5, "C2_d_a": C2 + ["-fea_delta", "d_a"],
         "C2_trap9": C2 + ["-fea_trap", "9"], "C2_cms_exp": C2 + ["-fea_Z_exp", "2000"], "C2_cms_block": C2 + ["-fea_Z_block", "2000"],
         "C2_d_a_cms": C2 + ["-fea_delta", "d_a", "-fea_Z_block", "2000"],
-        "exten_raw": "-fs 16000 -format_in raw -format_out raw -preset exten".split()}
+        "exten_raw": "-fs 16000 -format_in raw -format_out raw -preset exten".split(),
+        "C2_d_a_cmvn": C2 + ["-fea_delta", "d_a", "-stat_cmvn", "x.stat", "-apply_cmvn", "x.stat"]}
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="C3")
 ap.add_argument("--utts", type=int, default=2000)
@@ -48,6 +49,20 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 bpf = 2 * eng.dims.wshift + 4 * eng.dims.row_floats + (1 if eng.dims.has_vad else 0)
+if "-stat_cmvn" in cfg:  # the three CMVN passes over the resident rows (64 synthetic speakers)
+    spk = (np.arange(plan.n_utt) % 64).astype(np.int32)
+    def passes():
+        acc = eng.cmvn_accumulate(plan, rows, spk, 64)
+        mean = acc[:, :-1] / acc[:, -1:]
+        acc2 = eng.cmvn_accumulate(plan, rows, spk, 64, mean=mean)
+        var = acc2[:, :-1] / (acc2[:, -1:] - 1)
+        eng.cmvn_apply(plan, rows, spk, 64, mean, var * 0 + 1)   # unit "variance": repeated runs stay finite
+        torch.cuda.synchronize()
+    passes()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        passes()
+    print(json.dumps({"cfg": a.cfg, "cmvn_three_passes_ms": (time.perf_counter() - t0) / a.steps * 1e3, "frames": plan.total_frames}))
 print(json.dumps({"cfg": a.cfg, "frames": plan.total_frames, "ms_per_step": dt * 1e3, "frames_per_s": plan.total_frames / dt,
                   "front_kernel_ms": eng.last_kernel_ms(), "bytes_per_frame": bpf,
                   "hbm_frac": plan.total_frames * bpf / dt / 8e12}))
