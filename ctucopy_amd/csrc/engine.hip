@@ -1478,27 +1478,37 @@ __global__ __launch_bounds__(256) void cms_block_kernel(const float *__restrict_
 // Row N2, CMVN part (src/fea/post_impl.cc:51-118).  One workgroup per 64-frame chunk; thread = statistic slot.
 // HBM-bound: every row is read once per pass (coalesced: consecutive slots are consecutive columns but for the rotated
 // c0 entries), partial sums in double, one fp64 atomic per (chunk, slot).
-__global__ __launch_bounds__(128) void cmvn_accumulate_kernel(const float *__restrict__ rows, const int4 *__restrict__ utt_info,
+__global__ __launch_bounds__(256) void cmvn_accumulate_kernel(const float *__restrict__ rows, const int4 *__restrict__ utt_info,
                                                               const int *__restrict__ chunks, const int *__restrict__ spk_of_utt,
                                                               const int *__restrict__ col_of_slot, const double *__restrict__ mean,
                                                               double *__restrict__ acc, int cols, int D) {
+    __shared__ double part[4][128];
     const int u = chunks[2 * blockIdx.x], t0 = chunks[2 * blockIdx.x + 1];
     const int4 ui = utt_info[u];
     const long long ro = (long long)(unsigned)ui.x | ((long long)ui.y << 32);
     const int n = min(64, ui.z - t0), spk = spk_of_utt[u];
-    for (int k = threadIdx.x; k < cols; k += 128) {
-        const float *src = rows + (ro + t0) * D + col_of_slot[k];
+    // thread = (row group rg of four, statistic slot): the 64 rows of a chunk are summed in four interleaved groups,
+    // combined through LDS, then one fp64 atomic per (chunk, slot)
+    const int rg = threadIdx.x >> 6, kl = threadIdx.x & 63;
+    for (int k0 = 0; k0 < cols; k0 += 64) {
+        const int k = k0 + kl;
         double sum = 0.0;
-        if (mean) {
-            const double m = mean[(size_t)spk * cols + k];
-            for (int t = 0; t < n; t++) {
-                const double dlt = (double)src[(size_t)t * D] - m;
-                sum += dlt * dlt;
+        if (k < cols) {
+            const float *src = rows + (ro + t0) * D + col_of_slot[k];
+            if (mean) {
+                const double m = mean[(size_t)spk * cols + k];
+                for (int t = rg; t < n; t += 4) {
+                    const double dlt = (double)src[(size_t)t * D] - m;
+                    sum += dlt * dlt;
+                }
+            } else {
+                for (int t = rg; t < n; t += 4) sum += (double)src[(size_t)t * D];
             }
-        } else {
-            for (int t = 0; t < n; t++) sum += (double)src[(size_t)t * D];
         }
-        atomicAdd(&acc[(size_t)spk * (cols + 1) + k], sum);
+        part[rg][kl] = sum;
+        __syncthreads();
+        if (rg == 0 && k < cols) atomicAdd(&acc[(size_t)spk * (cols + 1) + k], (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]));
+        __syncthreads();
     }
     if (threadIdx.x == 0) atomicAdd(&acc[(size_t)spk * (cols + 1) + cols], (double)n);
 }
@@ -2636,7 +2646,7 @@ int ctu_cmvn_accumulate(ctu_engine *e, const ctu_plan *pl, const float *d_rows, 
         std::vector<double> zero((size_t)n_spk * (cols + 1), 0.0);
         e->d_stat_a.upload(zero);
         if (mean) e->d_stat_b.upload(std::vector<double>(mean, mean + (size_t)n_spk * cols));
-        hipLaunchKernelGGL(cmvn_accumulate_kernel, dim3(pl->n_trap_chunks), dim3(128), 0, s, d_rows, pl->utt_info.p,
+        hipLaunchKernelGGL(cmvn_accumulate_kernel, dim3(pl->n_trap_chunks), dim3(256), 0, s, d_rows, pl->utt_info.p,
                            pl->trap_chunks.p, e->d_spk.p, e->d_col_of_slot.p, mean ? e->d_stat_b.p : nullptr, e->d_stat_a.p,
                            cols, e->design->D);
         HIP_TRY(hipGetLastError());
