@@ -1,0 +1,592 @@
+// frontend_kernel: PCM -> window -> FFT -> |.|^2 -> (exten NR) -> filter bank -> log -> DCT / LPC -> rows.
+// Included by engine.hip (one translation unit: the kernels and their host launchers share types).
+#pragma once
+
+namespace {
+
+// NZ = number of 32-sample rows that can hold non-zero input (ceil(window/32)); rows >= NZ are
+// literal zeros so the compiler prunes the first butterflies.
+#ifndef CTU_LB
+#define CTU_LB 4        // waves per SIMD the register allocator must leave room for (2 workgroups x 8 waves / 4 SIMDs)
+#endif
+#ifndef CTU_STAMP
+#define CTU_STAMP 0     // diagnostic build: per-wave s_memtime sums per code segment (never in production)
+#endif
+#if CTU_STAMP
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long now_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st_acc[i] += now_ - st_prev;                                                               \
+        st_prev = now_;                                                                            \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#ifndef CTU_B64A
+#define CTU_B64A 0      // experiment: one-pass float2 transpose in the first pass (raises register pressure: spills)
+#endif
+#ifndef CTU_LDSDMA
+#define CTU_LDSDMA 0    // experiment: second pass's PCM by LDS-DMA during the first pass (no gain, costs LDS cycles)
+#endif
+// MODE 0: 512-point real FFT, one frame per 16-lane group, NZ = rows of 32 samples, two passes of 4 frames.
+// MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
+//         (no twiddles in the untangle), NZ = rows of 16 samples, one pass of 8 frames.
+// VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
+// NC:     coefficients accumulated per frame in phase 2 (16 or MAXC): a compile-time width keeps eight accumulators
+//         and a code path out of the common instantiation (9 -> 2 spilled VGPRs, +5 %).
+// GEN:    false = the plain chain (DC removal on, power spectrum, no -fea_E, no exten, no intensity-loudness law, no
+//         diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills (+4 %).
+template <int NZ, int FEAT, int MODE, bool VX, int NC, bool GEN>
+__global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
+    const int o_e_mode = GEN ? p.e_mode : 0, o_dbg = GEN ? p.dbg : 0;
+    const bool o_fb_inld = GEN ? p.fb_inld != 0 : false, o_nr_exten = GEN ? p.nr_exten != 0 : false;
+    const bool o_fb_power = GEN ? p.fb_power != 0 : true, o_remove_dc = GEN ? p.remove_dc != 0 : true;
+    const bool o_skip_phase2 = GEN ? p.skip_phase2 != 0 : false;
+    extern __shared__ __align__(16) float lds[];
+    float *Pt = lds;                       // [TILE][PSTRIDE]
+    float *ltab = lds + TILE * PSTRIDE;    // phase-2 tables (layout: KParams)
+    float *ltw = ltab + p.tab_floats;      // [16][LTW_STRIDE] per-lane constant records
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
+    const int fg = lane >> 4;    // frame slot within the wave pass
+    const int partner = ((lane & 48) | ((16 - l16) & 15)) << 2;  // byte address for ds_bpermute
+    ci32 *slot_chunk = as_const(p.itab), *row_slot = slot_chunk + p.NS + 1;
+    cf32 *ftab = as_const(p.ftab);
+    for (int i = tid; i < p.tab_floats; i += WG) ltab[i] = p.ftab[i];
+    for (int i = tid; i < 16 * LANEC; i += WG) ltw[(i / LANEC) * LTW_STRIDE + (i % LANEC)] = p.lanec[i];
+    // Phase 2 reads whole 4-bin chunks, so bins a frame never writes (row padding 257..259; everything above bin
+    // 128 in the 256-point mode) are read under zero weights: start the tile finite.  Only finite values (spectra,
+    // transpose scratch) are ever written afterwards.
+    for (int i = tid; i < TILE * PSTRIDE; i += WG) Pt[i] = 0.f;
+    __syncthreads();
+    const float4 *lc = reinterpret_cast<const float4 *>(ltw + l16 * LTW_STRIDE);  // this lane's constant record
+    const float4 *ltw4 = lc + (LC_TW >> 2);                                       // [0,8) stage twiddles, [8,12) untangle
+
+#if CTU_STAMP
+    unsigned long long st_acc[16] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+    int tile = as_const(p.wg_first)[blockIdx.x];
+    if (tile < 0) return;
+    TileRec rec = load_rec(p.tiles, tile);
+
+    // samples x[i0-2 .. i0+1] of row j of frame slot f sit at pcm + sbase + f*wshift + 32 j + 2 l16 - 2
+    auto pcm_ptr = [&](const TileRec &r, int it) {
+        const int f = wave * 8 + it * 4 + fg;
+        const int fc = f < r.nvalid ? f : r.nvalid - 1;  // clamp: duplicates are computed but never stored
+        return p.pcm + r.sbase + (int64_t)fc * p.wshift + 2 * l16 - 2;
+    };
+    // exten NR state: thread = bin
+    float navg = 0.95f, yavg = 0.05f;
+
+    while (true) {
+        const int nvalid = rec.nvalid;
+        const int64_t rbase = rec.rbase;
+        const int next = rec.next;
+        TileRec nrec = rec;
+        if (next >= 0) nrec = load_rec(p.tiles, next);
+        // this wave owns frame slots [8*wave, 8*wave+8) of the tile and the P rows of the same numbers
+        const int nv = min(max(nvalid - wave * 8, 0), 8);
+
+        // ================= phase 1: frames -> power spectrum rows =================
+        // Pass A (frame slots 0-3 of the wave) loads its PCM from global memory and meanwhile has the PCM of
+        // pass B (slots 4-7) copied by LDS-DMA into the wave's rows 4-7, which nobody needs before pass B
+        // writes its spectra there.  The transpose scratch is rows 0-3 in pass A and rows 4-7 in pass B.
+        constexpr bool DMA = CTU_LDSDMA && (NZ <= 15) && MODE == 0;  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
+        if (o_dbg != 2 && nv > 0) {
+            const int npass = (MODE == 0 && nv > 4) ? 2 : 1;
+            // the pass body is instantiated twice (it = 0, 1) so that the choice of transpose is made at compile time
+            auto pass = [&](auto IT) {
+                constexpr int it = decltype(IT)::value;
+                const int f = wave * 8 + it * 4 + fg;  // frame slot in tile
+                const bool file_start = (l16 == 0) && (rec.t0 + (f < nvalid ? f : nvalid - 1) == 0);
+                float *scratch = Pt + (wave * 8 + (DMA ? 4 * it : 4)) * PSTRIDE;
+                STAMP(0);  // loop overhead / previous tail
+                float2 v[16];
+                if constexpr (MODE == 1) {
+                    // frames A = slot 2*fg, B = A+1 of this wave's 8; sample n = 16 j + l16 of each goes to re / im
+                    const int fa = wave * 8 + 2 * fg, fb_ = fa + 1;
+                    const int ca = fa < nvalid ? fa : nvalid - 1, cb_ = fb_ < nvalid ? fb_ : nvalid - 1;
+                    const int16_t *xa = p.pcm + rec.sbase + (int64_t)ca * p.wshift + l16;
+                    const int16_t *xb = p.pcm + rec.sbase + (int64_t)cb_ * p.wshift + l16;
+                    const bool start_a = (l16 == 0) && (rec.t0 + ca == 0), start_b = (l16 == 0) && (rec.t0 + cb_ == 0);
+                    float dca = 0.f, dcb = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];
+                        const float w = (j & 1) ? w4.z : w4.x;  // 0 beyond the window
+                        float pa = (float)xa[16 * j - 1], pb = (float)xb[16 * j - 1];
+                        const float a0 = (float)xa[16 * j], b0 = (float)xb[16 * j];
+                        if (j == 0) {
+                            pa = start_a ? 0.f : pa;
+                            pb = start_b ? 0.f : pb;
+                        }
+                        const float ya = w * (a0 - p.preem * pa), yb = w * (b0 - p.preem * pb);
+                        v[j] = make_float2(ya, yb);
+                        dca += ya;
+                        dcb += yb;
+                    }
+#pragma unroll
+                    for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
+                    STAMP(1);
+                    if (o_remove_dc) {
+                        const float ma = row16_allreduce_add(dca) * p.inv_window, mb = row16_allreduce_add(dcb) * p.inv_window;
+#pragma unroll
+                        for (int j = 0; j < NZ; j++) {
+                            const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
+                            const float mm = (j & 1) ? mk.z : mk.x;
+                            v[j].x -= ma * mm;
+                            v[j].y -= mb * mm;
+                        }
+                    }
+                } else {
+                float dc = 0.f;
+                pcm4 q[NZ];
+                if (!DMA || it == 0) {
+                    const int16_t *x = pcm_ptr(rec, it);
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) q[j] = *reinterpret_cast<const pcm4 *>(x + 32 * j);
+                    if (DMA && npass == 2) {
+                        const int cl = lane < (32 * NZ + 8) / 8 ? lane : (32 * NZ + 8) / 8 - 1;  // 8-sample chunks of a frame
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int fb = wave * 8 + 4 + k;
+                            const int16_t *src = p.pcm + rec.sbase + (int64_t)(fb < nvalid ? fb : nvalid - 1) * p.wshift - 8 + 8 * cl;
+                            __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)(Pt + (wave * 8 + 4) * PSTRIDE + 256 * k), 16, 0, 0);
+                        }
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA issued in pass A has landed
+                    const uint32_t *lp = reinterpret_cast<const uint32_t *>(Pt + (wave * 8 + 4) * PSTRIDE + 256 * fg) + 3 + l16;
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        q[j].lo = lp[16 * j];
+                        q[j].hi = lp[16 * j + 1];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int j = 0; j < NZ; j++) {
+                    const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
+                    const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
+                    float xm = (float)(int16_t)(q[j].lo >> 16);
+                    const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
+                    const float x1 = (float)(int16_t)(q[j].hi >> 16);
+                    if (j == 0) xm = file_start ? 0.f : xm;  // first sample of the file: history is 0
+                    const float y0 = w0 * (x0 - p.preem * xm);
+                    const float y1 = w1 * (x1 - p.preem * x0);  // w is 0 beyond the window
+                    v[j] = make_float2(y0, y1);
+                    dc += y0 + y1;
+                }
+#pragma unroll
+                for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
+                STAMP(1);  // PCM + window loads, convert, pre-emphasis, window
+                if (o_remove_dc) {
+                    // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
+                    const float m = row16_allreduce_add(dc) * p.inv_window;
+                    if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
+                            v[j].x -= m * ((j & 1) ? mk.z : mk.x);
+                            v[j].y -= m * ((j & 1) ? mk.w : mk.y);
+                        }
+                    } else {  // exact instantiation: rows < NZ-1 are fully inside the window
+                        const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
+#pragma unroll
+                        for (int j = 0; j < NZ - 1; j++) {
+                            v[j].x -= m;
+                            v[j].y -= m;
+                        }
+                        v[NZ - 1].x -= m * (((NZ - 1) & 1) ? mk.z : mk.x);
+                        v[NZ - 1].y -= m * (((NZ - 1) & 1) ? mk.w : mk.y);
+                    }
+                }
+
+                }
+                STAMP(2);  // DC removal
+                // ---- stage 1: DFT16 over n1 (registers), lane = n2; then twiddle W256^(n2*k1)
+                dft16(v);
+                __builtin_amdgcn_sched_barrier(0);  // twiddles are L1 hits: fetch them just in time, not across the DFT
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
+                    v[2 * h + 1] = cmul(v[2 * h + 1], make_float2(tw.x, tw.y));
+                    if (2 * h + 2 < 16) v[2 * h + 2] = cmul(v[2 * h + 2], make_float2(tw.z, tw.w));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(3);  // DFT16 #1 + twiddles
+                // ---- transpose [k1][n2] -> lane k1 holds all n2, through LDS.
+                //      element (k1,n2) of frame slot fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1): conflict-free
+                //      both ways.  Pass A has all 8 rows of the wave free: one pass of float2 (b64).  Pass B has only
+                //      rows 4-7 (rows 0-3 already hold pass A's spectra): re then im (b32).
+                const int sw = fg * 256;
+                const int par = fg & 1;
+                __builtin_amdgcn_wave_barrier();
+                if (CTU_B64A && !DMA && it == 0) {
+                    float2 *sc2 = reinterpret_cast<float2 *>(Pt + wave * 8 * PSTRIDE);
+#pragma unroll
+                    for (int k1 = 0; k1 < 16; k1++) sc2[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; n2++) v[n2] = sc2[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+#pragma unroll
+                    for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].x;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    float re[16];
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; n2++) re[n2] = scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].y;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+
+                STAMP(4);  // LDS transpose
+                // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
+                dft16(v);
+                STAMP(5);  // DFT16 #2
+
+                if constexpr (MODE == 1) {
+                    // two real frames in one complex FFT: XA[k] = (Z[k] + conj Z[256-k])/2, XB[k] = (Z[k] - conj Z[256-k])/2i;
+                    // bins 0..128 of both; the mirror bin comes from lane (16-k1)%16 as in MODE 0
+                    float *pa = Pt + (wave * 8 + 2 * fg) * PSTRIDE, *pb = pa + PSTRIDE;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) {
+                        if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
+                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        if (l16 == 0) {
+                            br = v[(16 - k2) & 15].x;
+                            bi = v[(16 - k2) & 15].y;
+                        }
+                        const float ar = v[k2].x, ai = v[k2].y;
+                        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                        const int k = l16 + 16 * k2;
+                        pa[k] = 0.25f * (sr * sr + si * si);
+                        pb[k] = 0.25f * (dr * dr + di * di);
+                        if (VX && p.vad_export == 1) {  // XA = s/2, XB = (d)/(2i) = (di - i dr)/2
+                            const int fa = wave * 8 + 2 * fg;
+                            if (fa < nvalid) p.xri[(rbase + fa) * 129 + k] = make_float2(0.5f * sr, 0.5f * si);
+                            if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + k] = make_float2(0.5f * di, -0.5f * dr);
+                        }
+                    }
+                    if (l16 == 0) {
+                        pa[128] = v[8].x * v[8].x;
+                        pb[128] = v[8].y * v[8].y;
+                        if (o_remove_dc) pa[0] = pb[0] = 1e-10f;
+                        if (VX && p.vad_export == 1) {
+                            const int fa = wave * 8 + 2 * fg;
+                            if (fa < nvalid) p.xri[(rbase + fa) * 129 + 128] = make_float2(v[8].x, 0.f);
+                            if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + 128] = make_float2(v[8].y, 0.f);
+                        }
+                    }
+                } else {
+                // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
+                //      each together with its mirror bin 256-k held by lane (16-k1)%16 in register 15-k2
+                //      (register (16-k2)%16 for k1 = 0).
+                float *prow = Pt + f * PSTRIDE;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) {
+                    if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // two batches: bounds the registers in flight
+                    const float4 u4q = ltw4[8 + (k2 >> 1)];
+                    float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
+                    float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                    if (l16 == 0) {
+                        br = v[(16 - k2) & 15].x;
+                        bi = v[(16 - k2) & 15].y;
+                    }
+                    const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
+                    const float ar = v[k2].x, ai = v[k2].y;
+                    const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                    const float tr = wr * di + wi * dr;
+                    const float ti = wi * di - wr * dr;
+                    const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
+                    const float pk = 0.25f * (ur * ur + ui * ui);
+                    const float pm = 0.25f * (vr * vr + vi * vi);
+                    const int k = l16 + 16 * k2;
+                    prow[k] = pk;
+                    prow[256 - k] = pm;
+                    if (VX && p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
+                        float2 *xo = p.xri + (rbase + f) * 257;
+                        xo[k] = make_float2(0.5f * ur, 0.5f * ui);
+                        xo[256 - k] = make_float2(0.5f * vr, -0.5f * vi);
+                    }
+                }
+                if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
+                    prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
+                    if (o_remove_dc) prow[0] = 1e-10f;
+                    if (VX && p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
+                }
+                }
+                STAMP(6);  // untangle + P writes
+            };
+            pass(std::integral_constant<int, 0>{});
+            if (npass == 2) pass(std::integral_constant<int, 1>{});
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        if (!o_fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
+            for (int e = lane; e < nv * p.K; e += 64) {
+                const int f = e / p.K, k = e - f * p.K;
+                float *q_ = Pt + (wave * 8 + f) * PSTRIDE + k;
+                *q_ = sqrtf(*q_);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
+        // The only cross-wave step: one lane per bin walks the tile's frames in order (workgroup barriers).
+        if (o_nr_exten) {
+            __syncthreads();
+            if (rec.t0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
+                navg = 0.95f;
+                yavg = 0.05f;
+            }
+            if (tid < p.K) {
+                const float pp = p.nr_p, qq = 1.0f - p.nr_p;
+                for (int f = 0; f < nvalid; f++) {
+                    const float X = Pt[f * PSTRIDE + tid];
+                    // H = Navg / (Navg^a + Yavg^a)^(1/a); the output X - H X is formed as X (1 - H) with 1 - H written
+                    // without cancellation (fp32 here, double in the reference; double was measured: no accuracy gain,
+                    // -15 % on the main path through register allocation)
+                    // (v_rcp_f32 / v_rsq_f32, ~1 ulp, instead of IEEE division and square root: this loop is a serial chain)
+                    float H, omH;
+                    if (p.nr_a == 1.0f) {
+                        const float ir = __builtin_amdgcn_rcpf(navg + yavg);
+                        H = navg * ir;
+                        omH = yavg * ir;
+                    } else if (p.nr_a == 2.0f) {
+                        const float r2 = navg * navg + yavg * yavg;
+                        const float ir = __builtin_amdgcn_rsqf(r2);
+                        const float r = r2 * ir;
+                        H = navg * ir;
+                        omH = (yavg * yavg) * __builtin_amdgcn_rcpf(r * (r + navg));
+                    } else {
+                        H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
+                        omH = 1.0f - H;
+                    }
+                    const float N = H * X;
+                    navg = pp * navg + qq * N;
+                    yavg = fabsf(X - navg);
+                    Pt[f * PSTRIDE + tid] = X * omH;
+                }
+            }
+            __syncthreads();
+        }
+        if (VX && p.vad_export && nv > 0) {  // the VAD looks at in->_Xsabs after NR (src/io/batch.cc:230-240, src/vad/vad.cc:96-107,227-230)
+            if (p.vad_export == 1) {
+                for (int e = lane; e < nv * p.K; e += 64) {
+                    const int f = e / p.K, k = e - f * p.K;
+                    p.pnr[(rbase + wave * 8 + f) * p.K + k] = Pt[(wave * 8 + f) * PSTRIDE + k];
+                }
+            } else {
+                const int f8e = lane >> 3, ge = lane & 7;
+                float es = 0.f;
+                for (int k = ge; k < p.K; k += 8) {
+                    const float x = Pt[(wave * 8 + f8e) * PSTRIDE + k];
+                    es += x * x;
+                }
+                es = lanes8_allreduce_add(es);
+                if (ge == 0 && f8e < nv) p.pnr[rbase + wave * 8 + f8e] = es;
+            }
+        }
+        STAMP(7);  // hand-over to phase 2 (incl. NR)
+
+        // ================= phase 2 (wave-local): lane = (frame, band group) =================
+        // The wave's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
+        // 8 bands of a slot have similar widths; every group walks the same number of 4-bin chunks per slot.
+        if (o_dbg != 1 && !o_skip_phase2 && nv > 0) {
+            const int f8 = lane >> 3, g = lane & 7;
+            const int fslot = wave * 8 + f8;
+            const bool fvalid = f8 < nv;
+            const float *prow2 = Pt + fslot * PSTRIDE;
+            float c[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) c[i] = 0.f;
+            float esum = 0.f;
+            if (o_e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
+                const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : wave * 8) * p.wshift;
+                for (int i = 1 + g; i < p.window; i += 8) {
+                    const float x = (float)xr[i];
+                    esum += x * x;
+                }
+            }
+            if (o_e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
+                for (int k = g; k < p.K; k += 8) {
+                    const float x = prow2[k];
+                    esum += ((k == 0 || k == p.K - 1) ? 0.5f : 1.0f) * x * x;
+                }
+            }
+            for (int sl = 0; sl < p.NS; sl++) {
+                const int cb = slot_chunk[sl], ce = slot_chunk[sl + 1];
+                // {first bin of the cell's chunk run, band index or -1}: the only per-lane indirection of the slot
+                const int kstart = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2]);
+                const int bidx = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2 + 1]);
+                const float4 *pq = reinterpret_cast<const float4 *>(prow2 + kstart);  // kstart is a multiple of 4
+                const float4 *wq = reinterpret_cast<const float4 *>(ltab) + cb * 8 + g;
+                float acc = 0.f, acc1 = 0.f;
+                const int nch = ce - cb;
+                int ch = 0;
+                for (; ch + 4 <= nch; ch += 4) {  // 4 chunks per group: 12 LDS reads in flight, then 16 FMAs
+                    float4 w4[4], p4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) w4[u] = wq[(ch + u) * 8];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) p4[u] = pq[ch + u];
+#pragma unroll
+                    for (int u = 0; u < 4; u += 2) {
+                        acc += w4[u].x * p4[u].x;
+                        acc1 += w4[u + 1].x * p4[u + 1].x;
+                        acc += w4[u].y * p4[u].y;
+                        acc1 += w4[u + 1].y * p4[u + 1].y;
+                        acc += w4[u].z * p4[u].z;
+                        acc1 += w4[u + 1].z * p4[u + 1].z;
+                        acc += w4[u].w * p4[u].w;
+                        acc1 += w4[u + 1].w * p4[u + 1].w;
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU
+                }
+                for (; ch < nch; ch++) {
+                    const float4 w4 = wq[ch * 8];
+                    const float4 p4 = pq[ch];
+                    acc += w4.x * p4.x;
+                    acc1 += w4.y * p4.y;
+                    acc += w4.z * p4.z;
+                    acc1 += w4.w * p4.w;
+                }
+                acc += acc1;
+                float y = acc;
+                if (o_fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
+                // v_log_f32 (log2, ~1 ulp) * ln 2: band energies of int16 speech are far from the denormal range
+                if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __builtin_amdgcn_logf(y) * 0.69314718056f;
+                if (o_e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
+                    esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5f : 1.0f) * acc * acc;
+                if (FEAT == FEAT_BANDS) {
+                    float *dst = p.band_to_scratch ? p.logmel : p.rows;
+                    const int out_w = p.band_to_scratch ? p.B : p.D;
+                    if (bidx >= 0 && fvalid) dst[(rbase + fslot) * out_w + bidx] = y;
+                } else {
+                    if (FEAT == FEAT_LP && !o_fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
+                    y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
+                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
+                    cell_accumulate<NC>(c, cf, y);
+                }
+            }
+            STAMP(8);  // filter bank + per-band accumulation
+            if (o_e_mode && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
+                float e = 0.f;
+                if (o_e_mode == 1 || o_e_mode == 3) e = __logf(2.0f * lanes8_allreduce_add(esum));
+                else if (o_e_mode == 4) e = __logf(lanes8_allreduce_add(esum));
+                if (o_e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
+            }
+            if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
+                cells_reduce<NC>(c);
+                float *orow = p.rows + (rbase + fslot) * p.D;
+                if (FEAT == FEAT_DCTC) {
+                    // c[r] = value of output slot r = sum_b dct[i(r)][b] * logY[b]  (norm, lifter and the writer's
+                    // c1..cN,c0 order are folded into the table on the host); lane g stores slots g, g+8, g+16
+#pragma unroll
+                    for (int h = 0; h < NC / 8; h++) {
+                        if (h * 8 < p.ncoef_out) {
+                            float val = c[h * 8];
+#pragma unroll
+                            for (int j = 1; j < 8; j++) val = (g == j) ? c[h * 8 + j] : val;
+                            if (fvalid && h * 8 + g < p.ncoef_out) orow[h * 8 + g] = val;
+                        }
+                    }
+                } else {
+                    // c[k] = R[k], the autocorrelation by cosine iDFT (src/fea/fea_impl.cc:181-198); every lane of the
+                    // frame runs Levinson-Durbin in double (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
+                    // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
+                    // fp32: with the cube-root (or squared) band energies the autocorrelation matrix is well
+                    // conditioned; measured deviation from a double recursion ~1e-6 (tests/test_gpu_parity.py::test_c3_plp)
+                    const int P_ = p.lporder;
+                    float a[MAX_LP + 1], cc[MAX_LP + 1];
+                    const float r0 = c[0];
+                    if (o_e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = __builtin_amdgcn_logf(r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
+                    float rc = -c[1] / r0;
+                    float err = r0 * (1 - rc * rc);
+                    a[0] = 1;
+                    a[1] = rc;
+#pragma unroll
+                    for (int ik = 2; ik <= MAX_LP; ik++) {
+                        if (ik <= P_ && ik < NC) {  // the host picks NC > lporder
+                            float dm = c[ik < NC ? ik : NC - 1];
+#pragma unroll
+                            for (int n = 1; n < ik; n++) dm += a[n] * c[ik - n];
+                            rc = -dm / err;
+#pragma unroll
+                            for (int n = 1; n <= ik / 2; n++) {
+                                const float lo = a[n], hi = a[ik - n];
+                                a[n] = lo + rc * hi;
+                                if (n != ik - n) a[ik - n] = hi + rc * lo;
+                            }
+                            a[ik] = rc;
+                            err *= (1 - rc * rc);
+                        }
+                    }
+                    if (p.lp_is_lpa) {
+#pragma unroll
+                        for (int i = 1; i <= MAX_LP; i++)
+                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = a[i];
+                    } else {
+                        cc[0] = __builtin_amdgcn_logf(err) * 0.69314718056f;
+#pragma unroll
+                        for (int n = 1; n <= MAX_LP; n++) {
+                            if (n <= p.ncep) {
+                                float sum = 0;
+#pragma unroll
+                                for (int k = 1; k < n; k++)
+                                    if (k <= P_) sum += (float)(n - k) * cc[n - k] * a[k];
+                                cc[n] = (n <= P_ ? -a[n] : 0.0f) - sum / (float)n;
+                            }
+                        }
+#pragma unroll
+                        for (int n = 0; n <= MAX_LP; n++) {
+                            if (n <= p.ncep) {
+                                float val = cc[n];
+                                if (n >= 1 && p.lifter_on) val *= ftab[p.lift_off + n - 1];
+                                const int slot = row_slot[n];
+                                if (slot >= 0 && fvalid && g == (n & 7)) orow[slot] = val;
+                            }
+                        }
+                    }
+                }
+            }
+            STAMP(10);  // reduction, tail, row store
+        }
+        if (o_nr_exten) __syncthreads();  // the bin-wise NR pass of the next tile reads every wave's rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (next < 0) break;
+        rec = nrec;
+    }
+#if CTU_STAMP
+    if (lane == 0 && p.stamps)
+        for (int i = 0; i < 16; i++) p.stamps[(blockIdx.x * NWAVE + wave) * 16 + i] = st_acc[i];
+#endif
+}
+
+}  // namespace

@@ -1,0 +1,174 @@
+// Constants, kernel parameter block and device helpers shared by the kernels.
+// Included by engine.hip (one translation unit: the kernels and their host launchers share types).
+#pragma once
+
+namespace {
+
+constexpr int TILE = 64;       // frames per tile (= lanes of the per-frame phase)
+constexpr int WG = 512;        // threads per workgroup (8 waves)
+constexpr int NWAVE = WG / 64;
+constexpr int PSTRIDE = 260;   // floats per P-tile row: 257 bins padded so rows stay 16-byte aligned (b128 reads in phase 2)
+constexpr int LDS_2WG = 80 * 1024;  // two workgroups per CU fit when a workgroup's LDS stays at or under this
+constexpr int MAX_LP = 16;     // Levinson order limit of the in-register recursion
+constexpr int MAXC = 24;       // most coefficients accumulated per frame in phase 2 (cepstra incl. c0, or LP lags)
+constexpr int PCM_ALIGN = 8;   // utterance starts are multiples of this many samples
+constexpr int PCM_HEAD = 8;    // samples of padding before the first utterance (x[-2..-1] of frame 0 is loaded)
+constexpr int PCM_TAIL = 64;   // padding after the last one (loads run to the end of the 32-sample row)
+
+// Per-lane constant record, one per l16 = lane & 15, streamed from L1 every pass instead of pinning
+// 70+ VGPRs:  [0,32) Hamming pairs (w[32j+2l], w[32j+2l+1]) j=0..15 | [32,64) 1/0 "sample is inside the
+// window" pairs for DC removal | [64,96) inter-stage twiddles W256^(l*k1), k1=1..15 (+pad) |
+// [96,112) W512^(l+16*k2), k2=0..7
+constexpr int LC_WIN = 0, LC_MASK = 32, LC_TW = 64, LC_UT = 96, LANEC = 112;
+// The records are copied into LDS per workgroup: PCM streaming keeps evicting them from L1 and a miss costs
+// ~1k cycles.  Row stride 116 floats makes the 16 lanes' ds_read_b128 conflict-free (116 mod 64 = 52).
+constexpr int LTW_STRIDE = 116, LTW_FLOATS = 16 * LTW_STRIDE;
+
+// Kernel variants by feature tail.  BANDS covers spec / logspec / the log-mel scratch of TRAP (runtime flags
+// band_log, band_to_scratch); LP covers lpc and lpa (runtime flag lp_is_lpa).
+enum FeatMode { FEAT_BANDS = 0, FEAT_DCTC = 2, FEAT_LP = 3 };
+
+struct KParams {
+    const int16_t *pcm;
+    float *rows;
+    float *logmel;              // [total_frames][B] scratch (TRAP only)
+    float2 *xri;                // [total_frames][K] complex spectrum before NR (VAD cepdist-lpc only)
+    float *pnr;                 // [total_frames][K] spectrum after NR (VAD cepdist-lpc) or [total_frames] energy (VAD energy)
+    int vad_export;             // 0 none, 1 spectra for the Burg-cepstral criterion, 2 frame energy criterion
+    int band_log, band_to_scratch, lp_is_lpa;
+    const struct TileRec *tiles;
+    const int *wg_first;        // [grid] first tile of each workgroup's chain (-1 = none)
+    const float *lanec;         // [16][LANEC]
+    const float *ftab;          // image of the LDS tables (tab_floats), then the lifter at lift_off
+    const int *itab;            // slot_chunk[NS+1] | row_slot[nfea]
+    // LDS tables (float index): chunk weights float4 [NC][8] at 0 | cell {first bin, band index or -1} (int2)
+    // [NS][8] at ck_off | per-cell coefficient rows [NS][8][CW] at cf_off
+    int tab_floats, ck_off, cf_off, NS, CW;
+    int ncoef_out;              // DCTC: coefficients written per row (table rows are in output order)
+    int e_mode, e_slot, K, window;  // -fea_E: 0 none, 1 spectrum (nr->E), 2 log R[0], 3 band energy, 4 raw frame energy
+    int wshift, B, nfea, D, ncep, lporder;
+    int lift_off;
+    float preem, inv_window;
+    int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
+    float nr_p, nr_a;
+    unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
+    int skip_phase2;  // signal output (row N3): spectra are exported, nothing is projected
+    int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// Radix-4 butterfly, forward transform (W4 = -i).
+__device__ __forceinline__ void bfly4(float2 &p0, float2 &p1, float2 &p2, float2 &p3) {
+    const float2 s02 = make_float2(p0.x + p2.x, p0.y + p2.y), d02 = make_float2(p0.x - p2.x, p0.y - p2.y);
+    const float2 s13 = make_float2(p1.x + p3.x, p1.y + p3.y), d13 = make_float2(p1.x - p3.x, p1.y - p3.y);
+    p0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+    p2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+    p1 = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i*d13
+    p3 = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i*d13
+}
+
+// In-register 16-point DFT, natural order in and out: x[n] -> X[k] = sum_n x[n] W16^(nk).
+// n = 4a+b, k = c+4d:  X[c+4d] = sum_b W4^(bd) * W16^(bc) * sum_a x[4a+b] W4^(ac).
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; b++) bfly4(v[b], v[4 + b], v[8 + b], v[12 + b]);  // v[4c+b] = y_b[c]
+    // twiddles W16^(b*c), b,c in 1..3
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(C1, -S1));                                   // W^1
+    v[4 * 1 + 2] = make_float2((v[4 * 1 + 2].x + v[4 * 1 + 2].y) * R2, (v[4 * 1 + 2].y - v[4 * 1 + 2].x) * R2);  // W^2
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], make_float2(S1, -C1));                                   // W^3
+    v[4 * 2 + 1] = make_float2((v[4 * 2 + 1].x + v[4 * 2 + 1].y) * R2, (v[4 * 2 + 1].y - v[4 * 2 + 1].x) * R2);  // W^2
+    v[4 * 2 + 2] = make_float2(v[4 * 2 + 2].y, -v[4 * 2 + 2].x);                                // W^4 = -i
+    v[4 * 2 + 3] = make_float2((v[4 * 2 + 3].y - v[4 * 2 + 3].x) * R2, -(v[4 * 2 + 3].x + v[4 * 2 + 3].y) * R2);  // W^6
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], make_float2(S1, -C1));                                   // W^3
+    v[4 * 3 + 2] = make_float2((v[4 * 3 + 2].y - v[4 * 3 + 2].x) * R2, -(v[4 * 3 + 2].x + v[4 * 3 + 2].y) * R2);  // W^6
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-C1, S1));                                   // W^9
+#pragma unroll
+    for (int c = 0; c < 4; c++) bfly4(v[4 * c + 0], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);  // v[4c+d] = X[c+4d]
+    // reorder to natural: X[k] sits at v[4*(k&3) + (k>>2)]
+    float2 t[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = v[4 * (k & 3) + (k >> 2)];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = t[k];
+}
+
+// Wave-uniform tables are read through constant-address-space pointers so that they become scalar
+// loads (s_load_dword*) into SGPRs instead of per-lane VMEM loads.
+typedef __attribute__((address_space(4))) const float cf32;
+typedef __attribute__((address_space(4))) const int ci32;
+typedef __attribute__((address_space(4))) const int64_t ci64;
+__device__ __forceinline__ cf32 *as_const(const float *p) { return (cf32 *)p; }
+__device__ __forceinline__ ci32 *as_const(const int *p) { return (ci32 *)p; }
+__device__ __forceinline__ ci64 *as_const(const int64_t *p) { return (ci64 *)p; }
+
+// Sum over the 16 lanes of a DPP row, result in every lane: four row-rotate adds on the VALU
+// (no LDS round trips, unlike __shfl_xor which lowers to ds_bpermute).
+__device__ __forceinline__ float row16_allreduce_add(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    return x;
+}
+
+// Sum over 8 consecutive lanes (a frame's band groups), result in all 8: xor-1, xor-2 inside quads, then the
+// mirrored half row brings in the other quad.
+__device__ __forceinline__ float lanes8_allreduce_add(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+    return x;
+}
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-byte aligned
+    uint32_t lo, hi;
+};
+
+// Phase-2 helpers with a compile-time coefficient count (16 or MAXC) so that nothing branches per coefficient.
+template <int NCW>
+__device__ __forceinline__ void cell_accumulate(float (&c)[NCW], const float4 *cf, float y) {
+    float4 k4[NCW / 4];
+#pragma unroll
+    for (int i = 0; i < NCW / 4; i++) k4[i] = cf[i];  // all loads first, then the FMAs
+#pragma unroll
+    for (int i = 0; i < NCW / 4; i++) {
+        c[4 * i + 0] += k4[i].x * y;
+        c[4 * i + 1] += k4[i].y * y;
+        c[4 * i + 2] += k4[i].z * y;
+        c[4 * i + 3] += k4[i].w * y;
+    }
+}
+template <int NCW>
+__device__ __forceinline__ void cells_reduce(float (&c)[NCW]) {
+#pragma unroll
+    for (int i = 0; i < NCW; i++) c[i] = lanes8_allreduce_add(c[i]);
+}
+
+// Tile record (32 bytes, read with one scalar load): where the tile's first frame starts in the PCM
+// arena, where its first output row goes, how many of its 64 frame slots are real, the frame index of
+// slot 0 inside its utterance, and the next tile this workgroup walks (-1 = done).
+struct TileRec {
+    int64_t sbase, rbase;
+    int nvalid, t0, next, pad;
+};
+
+__device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
+    ci32 *w = as_const(reinterpret_cast<const int *>(tiles)) + 8 * tile;
+    TileRec r;
+    r.sbase = ((int64_t)w[1] << 32) | (uint32_t)w[0];
+    r.rbase = ((int64_t)w[3] << 32) | (uint32_t)w[2];
+    r.nvalid = w[4];
+    r.t0 = w[5];
+    r.next = w[6];
+    r.pad = 0;
+    return r;
+}
+
+}  // namespace

@@ -1,0 +1,342 @@
+// VAD module: Burg-cepstral criterion per frame, decision replay per utterance.
+// Included by engine.hip (one translation unit: the kernels and their host launchers share types).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// VAD module (src/vad/vad.cc, src/vad/vad.h, src/vdet/Burg.h).  Decisions are discontinuous, so this side path
+// computes in double.  Kernel A is frame-parallel (HC2R of the post-NR spectrum with the original phase, Burg
+// lattice, a -> c); kernel B is one thread per utterance and replays the sequential part: cepstral distance to
+// the adaptive background, threshold recurrences, background update, majority ("median") filter.
+// ------------------------------------------------------------------------------------------------
+struct VadParams {
+    int K, wfft, window, ncoef;  // ncoef = vad_lpc_coefs (cepdist lpc) or feature vector length (cepdist fea)
+    int cri;                     // 0 energy, 1 cepdist-lpc, 2 cepdist-fea
+    int thr;                     // 0 absolute, 1 perc, 2 adapt, 3 dyn
+    int energy_db, cep_init, filter_order;
+    double cep_p, abs_thr, perc_thr, adapt_q, adapt_za, dyn_perc, dyn_min, qmaxinc, qmaxdec, qmindec, qmininc;
+    int perc_init, adapt_init, dyn_init;
+    int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
+};
+
+// One wave per frame (4 frames per 256-thread workgroup): the frame's samples live in registers, strided over the
+// lanes (sample j = lane + 64 q), reductions are wave shuffles, no workgroup barrier inside the lattice.
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+#ifndef CTU_VAD_REAL
+#define CTU_VAD_REAL double  // arithmetic of the HC2R + Burg kernel (float was measured: see DESIGN.md)
+#endif
+typedef CTU_VAD_REAL vreal;
+__device__ __forceinline__ vreal wave_sum_r(vreal x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// Row rotation by DPP for 32- and 64-bit values (v_mov_b32_dpp per half), and a wave all-reduce built on it: four
+// rotate-and-add steps inside each row of 16 lanes, then the four row sums through v_readlane.  A shuffle-based
+// butterfly (ds_bpermute) costs an LDS round trip per step; the lattice below runs two reductions per order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_read(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double lane_read(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+template <class T>
+__device__ __forceinline__ T wave_sum_fast(T x) {
+    x += dpp_mov<0x128>(x);  // row_ror:8
+    x += dpp_mov<0x124>(x);  // row_ror:4
+    x += dpp_mov<0x122>(x);  // row_ror:2
+    x += dpp_mov<0x121>(x);  // row_ror:1
+    return (lane_read(x, 0) + lane_read(x, 16)) + (lane_read(x, 32) + lane_read(x, 48));
+}
+
+struct vreal2 { vreal x, y; };
+__device__ __forceinline__ vreal2 vcmul(vreal2 a, vreal2 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+template <int Q, int NCMAX>  // samples per lane: window <= 64*Q; cepstral coefficients: ncoef <= NCMAX
+__global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
+                                                       double *__restrict__ ci_out, VadParams vp, int64_t total_frames) {
+    extern __shared__ __align__(16) unsigned char burg_lds[];
+    vreal2 *root = reinterpret_cast<vreal2 *>(burg_lds);  // [512] e^{+2 pi i m / 512}; then per wave 2 x [wfft/2 + 4] ping-pong
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = vp.K, n = vp.wfft, W = vp.window, nc = vp.ncoef;
+    for (int m = tid; m < 512; m += 256) {
+        double sd, cd;
+        sincospi((double)m / 256.0, &sd, &cd);
+        root[m] = {(vreal)cd, (vreal)sd};
+    }
+    __syncthreads();  // the only workgroup barrier; everything below is wave-local (persistent waves walk the frames)
+    const int M = n / 2, rs = 512 / n, mr = 512 / M;
+    vreal2 *A = root + 512 + (size_t)wave * 2 * (M + 4), *Bf = A + (M + 4);
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int64_t fr = (int64_t)blockIdx.x * 4 + wave; fr < total_frames; fr += (int64_t)gridDim.x * 4) {
+    for (int k = lane; k < K; k += 64) {  // halfcomplex input: Xa cos(phi), Xa sin(phi)   (src/vad/vad.cc:227-230)
+        const float2 x = xri[fr * K + k];
+        const vreal xa = pnr[fr * K + k];
+        vreal c = 1.0, s_ = 0.0;  // Xph[0] = 0 (src/io/in.cc:398)
+        if (k > 0) {
+            // direction of a float spectrum value: float arithmetic (v_rsq + one Newton step) is as exact as its input
+            const float mag2 = x.x * x.x + x.y * x.y;
+            if (mag2 > 0.f) {
+                float inv = __builtin_amdgcn_rsqf(mag2);
+                inv = inv * (1.5f - 0.5f * mag2 * inv * inv);
+                c = (vreal)(x.x * inv);
+                s_ = (vreal)(x.y * inv);
+            } else {  // c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193); the last bin is 0 or pi by the sign of re (:399)
+                c = (k == K - 1) ? 1.0 : 0.0;
+                s_ = (k == K - 1) ? 0.0 : -1.0;
+            }
+            if (k == K - 1) s_ = 0.0;
+        }
+        A[k] = {xa * c, (k == 0 || k == K - 1) ? (vreal)0.0 : xa * s_};  // FFTW's halfcomplex format has no imaginary DC / Nyquist
+    }
+    wave_sync();
+    // FFTW_HC2R, unnormalised: x_j = sum over the Hermitian extension of X_k e^{+2 pi i jk/n}.  Packed half-size form:
+    // Z[k] = (X[k] + X*[M-k]) + i e^{+2 pi i k/n} (X[k] - X*[M-k]),  z = IDFT_M(Z),  x[2m] = Re z[m], x[2m+1] = Im z[m]
+    for (int k = lane; k < M; k += 64) {
+        const vreal2 xa = A[k], xb = A[M - k];
+        const vreal2 sm = {xa.x + xb.x, xa.y - xb.y}, df = {xa.x - xb.x, xa.y + xb.y};
+        const vreal2 w = root[k * rs];
+        Bf[k] = {sm.x - (w.x * df.y + w.y * df.x), sm.y + (w.x * df.x - w.y * df.y)};
+    }
+    wave_sync();
+    vreal2 *src = Bf, *dst = A;
+    int Ns = 1;
+    while (Ns * 4 <= M) {  // radix-4 Stockham passes
+        const int q4 = M / 4;
+        for (int j = lane; j < q4; j += 64) {
+            const int kk = j % Ns, tstep = kk * (M / (4 * Ns)) * mr;
+            const vreal2 v0 = src[j];
+            const vreal2 v1 = vcmul(src[j + q4], root[tstep & 511]);
+            const vreal2 v2 = vcmul(src[j + 2 * q4], root[(2 * tstep) & 511]);
+            const vreal2 v3 = vcmul(src[j + 3 * q4], root[(3 * tstep) & 511]);
+            const vreal2 s02 = {v0.x + v2.x, v0.y + v2.y}, d02 = {v0.x - v2.x, v0.y - v2.y};
+            const vreal2 s13 = {v1.x + v3.x, v1.y + v3.y}, d13 = {v1.x - v3.x, v1.y - v3.y};
+            const int base = (j / Ns) * Ns * 4 + kk;
+            dst[base] = {s02.x + s13.x, s02.y + s13.y};
+            dst[base + Ns] = {d02.x - d13.y, d02.y + d13.x};
+            dst[base + 2 * Ns] = {s02.x - s13.x, s02.y - s13.y};
+            dst[base + 3 * Ns] = {d02.x + d13.y, d02.y - d13.x};
+        }
+        wave_sync();
+        vreal2 *t_ = src; src = dst; dst = t_;
+        Ns *= 4;
+    }
+    if (Ns < M) {  // radix-2 tail (M = 128)
+        const int h = M / 2;
+        for (int j = lane; j < h; j += 64) {
+            const int kk = j % Ns;
+            const vreal2 v0 = src[j], v1 = vcmul(src[j + h], root[(kk * (M / (2 * Ns)) * mr) & 511]);
+            const int base = (j / Ns) * Ns * 2 + kk;
+            dst[base] = {v0.x + v1.x, v0.y + v1.y};
+            dst[base + Ns] = {v0.x - v1.x, v0.y - v1.y};
+        }
+        wave_sync();
+        vreal2 *t_ = src; src = dst; dst = t_;
+    }
+    vreal ef[Q], eb[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int j = lane + 64 * q;
+        const vreal2 z = src[(j >> 1) & (M - 1)];
+        ef[q] = (j & 1) ? z.y : z.x;
+    }
+    wave_sync();  // the buffers are free for the next frame once every lane has its samples
+    vreal part = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        if (lane + 64 * q >= W) ef[q] = 0.0;  // only the first `window` samples go to Burg (src/vad/vad.cc:233)
+        eb[q] = ef[q];
+        part += ef[q] * ef[q];
+    }
+    vreal alpha = wave_sum_fast(part) / (vreal)W;
+    // Burg lattice (src/vdet/Burg.h:49-95).  Prediction coefficients live one per lane (lane i = a[i]); the order
+    // update a'[i] = a[i] + rc a[ik-i] is one cross-lane read.
+    vreal acoef = lane == 0 ? (vreal)1.0 : (vreal)0.0;
+    for (int ik = 1; ik < nc; ik++) {
+        // eb[i-1]: the previous sample sits in the previous lane (or lane 63 of the previous q)
+        vreal ebm[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const vreal up = dpp_mov<0x138>(eb[q]);  // wave_shr:1
+            const vreal wrap = q > 0 ? lane_read(eb[q > 0 ? q - 1 : 0], 63) : (vreal)0.0;
+            ebm[q] = lane == 0 ? wrap : up;
+        }
+        vreal num = 0.0, den = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = lane + 64 * q;
+            if (i >= ik && i < W) {
+                den += ef[q] * ef[q] + ebm[q] * ebm[q];
+                num += ef[q] * ebm[q];
+            }
+        }
+        num = wave_sum_fast(num);
+        den = wave_sum_fast(den);
+        const vreal rc = -(2.0 * num) / den;
+        alpha *= 1.0 - rc * rc;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = lane + 64 * q;
+            if (i >= 1 && i < W) {  // both updates use the old values
+                const vreal nef = ef[q] + rc * ebm[q], neb = ebm[q] + rc * ef[q];
+                ef[q] = nef;
+                eb[q] = neb;
+            }
+        }
+        const vreal other = __shfl(acoef, (ik - lane) & 63, 64);
+        acoef = (lane >= 1 && lane < ik) ? acoef + rc * other : (lane == ik ? rc : acoef);
+    }
+    // Burg2Cepstrum (src/vdet/Burg.h:141-152) in registers, the same in every lane; lane m keeps c[m] for the store
+    {
+        vreal av[NCMAX], cc[NCMAX];
+#pragma unroll
+        for (int i = 0; i < NCMAX; i++) av[i] = lane_read(acoef, i);
+        cc[0] = (vreal)log((double)alpha);
+        vreal mine = cc[0];
+#pragma unroll
+        for (int m = 1; m < NCMAX; m++) {
+            vreal sum = 0.0;
+#pragma unroll
+            for (int k = 1; k < m; k++) sum += (vreal)(m - k) * cc[m - k] * av[k];
+            cc[m] = -av[m] - sum * (vreal)(1.0 / m);
+            mine = lane == m ? cc[m] : mine;
+        }
+        if (lane < nc) ci_out[fr * nc + lane] = (double)mine;
+    }
+    }  // frames
+}
+
+// One wave per utterance (src/vad/vad.cc:220-294 distance + background, :329-625 thresholds, vad.h:126-175 filter).
+// The recurrences are sequential in t; the wave stages 64 frames of criterion inputs in LDS with coalesced loads,
+// then every lane replays them (same values in all lanes, lane 0 writes).
+__global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
+                                                         const float *__restrict__ rows, const int64_t *__restrict__ row_off,
+                                                         int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
+    __shared__ double stage[64 * 32];
+    const int u = blockIdx.x, lane = threadIdx.x;
+    if (u >= n_utt) return;
+    const int64_t r0 = row_off[u];
+    const int T = (int)(row_off[u + 1] - r0);
+    const int nc = vp.cri == 0 ? 1 : vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
+    // majority filter (src/vad/vad.h:126-175): the last `order` (<= 31) raw decisions as bits, with a running count
+    unsigned long long hist = 0;
+    int hidx = 0, nout = 0, nsum = 0;
+    auto push = [&](int v) {
+        const int old = (int)((hist >> hidx) & 1ull);
+        hist = (hist & ~(1ull << hidx)) | ((unsigned long long)v << hidx);
+        nsum += v - old;
+        hidx = (hidx + 1 == order) ? 0 : hidx + 1;
+    };
+    double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
+    int adapt_vad = 0;
+    double c0r = 0.0;  // background cepstrum, coefficient `lane` (src/vad/vad.cc:220-294)
+    for (int tb = 0; tb < T; tb += 64) {
+        const int nt = min(64, T - tb);
+        __syncthreads();
+        if (vp.cri == 0) {
+            if (lane < nt) stage[lane] = cri_energy[r0 + tb + lane];
+        } else if (vp.cri == 1) {
+            for (int e = lane; e < nt * nc; e += 64) stage[e] = ci_all[(r0 + tb) * nc + e];
+        } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131)
+            for (int e = lane; e < nt * nc; e += 64) {
+                const int f = e / nc, i = e - f * nc;
+                const float *row = rows + (r0 + tb + f) * vp.D;
+                stage[e] = i == 0 ? (vp.c0_slot >= 0 ? (double)row[vp.c0_slot] : 0.0) : (double)row[i - 1];
+            }
+        }
+        __syncthreads();
+        for (int tt = 0; tt < nt; tt++) {
+            const int t = tb + tt;
+            double cri, cil = 0.0;
+            if (vp.cri == 0) {
+                double en = stage[tt];
+                if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
+                cri = en;
+            } else {
+                cil = lane < nc ? stage[tt * nc + lane] : 0.0;
+                if (t == 0) {
+                    c0r = cil;
+                    cri = 0.0;
+                } else {
+                    if (t == 1) c0r = (c0r + cil) / 2.0;
+                    const double dl = (lane >= 1 && lane < nc) ? cil - c0r : 0.0;  // c0 itself is not part of the distance
+                    cri = 4.3429 * sqrt(2 * wave_sum_fast(dl * dl));
+                }
+            }
+            int vad0;
+            if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
+            else if (vp.thr == 1) {
+                if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
+                else {
+                    crimin = cri < crimin ? cri : crimin;
+                    crimax = cri > crimax ? cri : crimax;
+                }
+                vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
+            } else if (vp.thr == 2) {
+                if (t == 0) {
+                    crimean = cri;
+                    crimean2 = cri * cri;
+                    crivar = 0.0;
+                    adapt_vad = 0;
+                } else {
+                    const double thr = crimean + vp.adapt_za * sqrt(crivar);
+                    if (cri < thr || t <= vp.adapt_init) {
+                        crimean = vp.adapt_q * crimean + (1.0 - vp.adapt_q) * cri;
+                        crimean2 = vp.adapt_q * crimean2 + (1.0 - vp.adapt_q) * cri * cri;
+                        crivar = crimean2 - crimean * crimean;
+                        adapt_vad = 0;
+                    } else adapt_vad = 1;
+                }
+                vad0 = adapt_vad;
+            } else {
+                const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
+                if (t < init) {
+                    dmax = dmin = cri;
+                    vad0 = 0;
+                } else if (t == init) {
+                    dmax = (cri > dmax ? cri : dmax) + vp.dyn_min / 10.0;
+                    dmin = (cri < dmin ? cri : dmin) - vp.dyn_min / 10.0;
+                    vad0 = 0;
+                } else {
+                    dmax = dmax < cri ? vp.qmaxinc * dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * dmax + (1.0 - vp.qmaxdec) * cri;
+                    dmin = dmin > cri ? vp.qmindec * dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * dmin + (1.0 - vp.qmininc) * cri;
+                    const double dyn = dmax - dmin;
+                    vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
+                }
+            }
+            if (vp.cri != 0 && !(vad0 && t > vp.cep_init))  // background update (src/vad/vad.cc:288-294)
+                c0r = vp.cep_p * c0r + (1.0 - vp.cep_p) * cil;
+            push(vad0);
+            if (t >= h) {
+                if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
+                nout++;
+            }
+        }
+    }
+    for (int k = 0; k < h && nout < T; k++) {  // flush: zeros pushed (src/vad/vad.h:156-175)
+        push(0);
+        if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
+        nout++;
+    }
+}
+
+}  // namespace

@@ -1,6 +1,6 @@
 """Row N1 (delta / acceleration / third differences, -fea_trap stacking): the oracle replays the reference's
 streaming ring (src/fea/fea_delta.cc) literally; these tests pin what that ring computes against closed forms, the
-same closed forms the GPU pass implements (ctucopy_amd/csrc/engine.hip: post_kernel), and check geometry and header
+same closed forms the GPU pass implements (ctucopy_amd/csrc/post_kernels.h: post_kernel), and check geometry and header
 bits against src/io/out.cc:95-113,157-159 and the shipped example configs egs/conf/15_*, 17_*."""
 import numpy as np
 import pytest
