@@ -450,7 +450,7 @@ void build_tables(ctu_engine *e) {
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
 }
 
-template <int NZ, int MODE, bool VX, bool GEN>
+template <int NZ, int MODE, bool VX, int GEN>
 void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
 #define LAUNCH(F, NCW)                                                                                 \
     {                                                                                                  \
@@ -473,11 +473,16 @@ void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm
 
 template <int NZ, int MODE>
 void launch_vx(bool vx, int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
-    // the plain chain gets its own instantiation (see GEN); everything else, and every VAD-export run, is generic
-    const bool plain = !vx && kp.e_mode == 0 && !kp.fb_inld && !kp.nr_exten && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
-    if (vx) launch_nz<NZ, MODE, true, true>(feat, grid, s, kp, shm);
-    else if (plain) launch_nz<NZ, MODE, false, false>(feat, grid, s, kp, shm);
-    else launch_nz<NZ, MODE, false, true>(feat, grid, s, kp, shm);
+    // Specialised instantiations (see GEN in frontend_kernel.h): the plain chain, plain + intensity-loudness law for the
+    // 16-coefficient LP path (PLP), plain + exten for 16-coefficient DCT / band outputs.  Everything else, and every
+    // run with the VAD export, reads its flags at run time.
+    const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
+    const bool narrow = kp.CW == 16;
+    if (vx) launch_nz<NZ, MODE, true, GEN_FULL>(feat, grid, s, kp, shm);
+    else if (base && !kp.fb_inld && !kp.nr_exten) launch_nz<NZ, MODE, false, GEN_PLAIN>(feat, grid, s, kp, shm);
+    else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP) launch_nz<NZ, MODE, false, GEN_INLD>(FEAT_LP, grid, s, kp, shm);
+    else if (base && !kp.fb_inld && kp.nr_exten && narrow && feat != FEAT_LP) launch_nz<NZ, MODE, false, GEN_EXTEN>(feat, grid, s, kp, shm);
+    else launch_nz<NZ, MODE, false, GEN_FULL>(feat, grid, s, kp, shm);
 }
 
 std::vector<std::string> to_args(int argc, const char *const *argv) {

@@ -37,14 +37,17 @@ namespace {
 // VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
 // NC:     coefficients accumulated per frame in phase 2 (16 or MAXC): a compile-time width keeps eight accumulators
 //         and a code path out of the common instantiation (9 -> 2 spilled VGPRs, +5 %).
-// GEN:    false = the plain chain (DC removal on, power spectrum, no -fea_E, no exten, no intensity-loudness law, no
-//         diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills (+4 %).
-template <int NZ, int FEAT, int MODE, bool VX, int NC, bool GEN>
+// GEN:    GEN_PLAIN = the plain chain (DC removal on, power spectrum, no -fea_E, no exten, no intensity-loudness law,
+//         no diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills (+4 %).
+//         GEN_INLD / GEN_EXTEN = the plain chain plus exactly that option (PLP; C4's noise reduction); GEN_FULL reads
+//         every flag at run time.
+template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
-    const int o_e_mode = GEN ? p.e_mode : 0, o_dbg = GEN ? p.dbg : 0;
-    const bool o_fb_inld = GEN ? p.fb_inld != 0 : false, o_nr_exten = GEN ? p.nr_exten != 0 : false;
-    const bool o_fb_power = GEN ? p.fb_power != 0 : true, o_remove_dc = GEN ? p.remove_dc != 0 : true;
-    const bool o_skip_phase2 = GEN ? p.skip_phase2 != 0 : false;
+    constexpr bool FULL = GEN == GEN_FULL;
+    const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
+    const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
+    const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
+    const bool o_skip_phase2 = FULL ? p.skip_phase2 != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
     float *ltab = lds + TILE * PSTRIDE;    // phase-2 tables (layout: KParams)
