@@ -480,6 +480,16 @@ void launch_vx(bool vx, int feat, dim3 grid, hipStream_t s, const KParams &kp, s
     const bool narrow = kp.CW == 16;
     if (vx) launch_nz<NZ, MODE, true, GEN_FULL>(feat, grid, s, kp, shm);
     else if (base && !kp.fb_inld && !kp.nr_exten) launch_nz<NZ, MODE, false, GEN_PLAIN>(feat, grid, s, kp, shm);
+    else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP && kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) {
+        // the PLP preset exactly: order and number of cepstra fixed at compile time (LPO)
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12>), grid, dim3(WG), shm, s, kp);
+    }
     else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP) launch_nz<NZ, MODE, false, GEN_INLD>(FEAT_LP, grid, s, kp, shm);
     else if (base && !kp.fb_inld && kp.nr_exten && narrow && feat != FEAT_LP) launch_nz<NZ, MODE, false, GEN_EXTEN>(feat, grid, s, kp, shm);
     else launch_nz<NZ, MODE, false, GEN_FULL>(feat, grid, s, kp, shm);

@@ -41,7 +41,9 @@ namespace {
 //         no diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills (+4 %).
 //         GEN_INLD / GEN_EXTEN = the plain chain plus exactly that option (PLP; C4's noise reduction); GEN_FULL reads
 //         every flag at run time.
-template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN>
+// LPO:    LP order = number of cepstra when it is fixed at compile time (12: the PLP preset), 0 = run-time orders up to
+//         MAX_LP.  The unrolled Levinson / a->c tail then has no guards and no dead orders (22 spilled VGPRs -> 0).
+template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL;
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
@@ -525,8 +527,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
                     // fp32: with the cube-root (or squared) band energies the autocorrelation matrix is well
                     // conditioned; measured deviation from a double recursion ~1e-6 (tests/test_gpu_parity.py::test_c3_plp)
-                    const int P_ = p.lporder;
-                    float a[MAX_LP + 1], cc[MAX_LP + 1];
+                    constexpr int PM = LPO ? LPO : MAX_LP;
+                    const int P_ = LPO ? LPO : p.lporder, ncep_ = LPO ? LPO : p.ncep;
+                    float a[PM + 1], cc[PM + 1];
                     const float r0 = c[0];
                     if (o_e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = __builtin_amdgcn_logf(r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
                     float rc = -c[1] / r0;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     a[0] = 1;
                     a[1] = rc;
 #pragma unroll
-                    for (int ik = 2; ik <= MAX_LP; ik++) {
+                    for (int ik = 2; ik <= PM; ik++) {
                         if (ik <= P_ && ik < NC) {  // the host picks NC > lporder
                             float dm = c[ik < NC ? ik : NC - 1];
 #pragma unroll
@@ -552,13 +555,13 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     }
                     if (p.lp_is_lpa) {
 #pragma unroll
-                        for (int i = 1; i <= MAX_LP; i++)
+                        for (int i = 1; i <= PM; i++)
                             if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = a[i];
                     } else {
                         cc[0] = __builtin_amdgcn_logf(err) * 0.69314718056f;
 #pragma unroll
-                        for (int n = 1; n <= MAX_LP; n++) {
-                            if (n <= p.ncep) {
+                        for (int n = 1; n <= PM; n++) {
+                            if (n <= ncep_) {
                                 float sum = 0;
 #pragma unroll
                                 for (int k = 1; k < n; k++)
@@ -567,8 +570,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                             }
                         }
 #pragma unroll
-                        for (int n = 0; n <= MAX_LP; n++) {
-                            if (n <= p.ncep) {
+                        for (int n = 0; n <= PM; n++) {
+                            if (n <= ncep_) {
                                 float val = cc[n];
                                 if (n >= 1 && p.lifter_on) val *= ftab[p.lift_off + n - 1];
                                 const int slot = row_slot[n];
