@@ -210,6 +210,9 @@ Design::Design(const Opts &opts) : o(opts) {
     fb_last.resize(B);
     for (int b = 0; b < B; b++) {  // first non-zero, then the end of that non-zero run (src/fea/fb.cc:432-447)
         int k = 0;
+        // a filter that covers no bin has area 0; with -fb_norm the reference divides by it: NaN weights, NaN features
+        for (int i = 0; i < K; i++)
+            if (fb[b][i] != fb[b][i]) throw DesignError("FB: filter with no spectral bin (NaN weights in the reference)");
         while (k < K && fb[b][k] == 0) k++;
         if (k == K) throw DesignError("FB: filter with no spectral bin (undefined in the reference)");
         fb_first[b] = k++;

@@ -607,6 +607,10 @@ static int fb_design(ctuo_t *c) {
      * end of the array in the reference (undefined), so it is rejected here. */
     for (int b = 0; b < size; b++) {
         int k = 0;
+        /* a filter that covers no bin has area 0; with -fb_norm the reference divides by it (0/0): every weight of the
+         * row is NaN and so is every feature.  Rejected like the all-zero row. */
+        for (int i = 0; i < K; i++)
+            if (c->mat[b][i] != c->mat[b][i]) { set_err(c, "FB: filter with no spectral bin (NaN weights in the reference)"); return -1; }
         while (k < K && c->mat[b][k] == 0) k++;
         if (k == K) { set_err(c, "FB: filter with no spectral bin (undefined in the reference)"); return -1; }
         c->mat[b][K + 1] = k;

@@ -93,3 +93,48 @@ def test_phase2_chunk_tables_reproduce_the_filter_bank(cfg):
     cfg = [a for a in cfg if a not in ("-vad", "burg")]
     err, nchunks, nslots = config_table(cfg, "phase2_check")
     assert err == 0.0 and nchunks >= 1 and nslots >= 1
+
+
+def _random_cfg(rng):
+    fs = int(rng.choice([8000, 11025, 16000, 22050, 44100]))
+    w = float(rng.choice([10, 16, 20, 25, 32]))
+    s = float(rng.choice([5, 8, 10, 12.5, 16]))
+    scale = str(rng.choice(["mel", "bark", "lin", "expolog"]))
+    shape = str(rng.choice(["triang", "rect", "trapez"]))
+    nf = int(rng.integers(3, 41))
+    if rng.random() < 0.3:
+        lo, mid, hi = sorted(int(x) for x in rng.choice(np.arange(100, fs // 2, 50), 3, replace=False))
+        n1, n2 = int(rng.integers(2, 12)), int(rng.integers(2, 12))
+        definition = f"{lo}-{mid}Hz:1-{n1}/{n1}filters,{mid}-{hi}Hz:2-{n2}/{n2}filters"
+    else:
+        definition = f"{nf}filters"
+    cfg = ["-fs", str(fs), "-format_in", "raw", "-format_out", "htk", "-w", str(w), "-s", str(s), "-fb_scale", scale,
+           "-fb_shape", shape, "-fb_definition", definition, "-fb_norm", str(rng.choice(["on", "off"])),
+           "-fb_eqld", str(rng.choice(["on", "off"])), "-fea_kind", str(rng.choice(["dctc", "logspec", "lpc"])),
+           "-fea_ncepcoefs", str(int(rng.integers(4, 17))), "-fea_lporder", str(int(rng.integers(4, 17))),
+           "-fea_lifter", str(int(rng.choice([0, 1, 22, 30])))]
+    return cfg
+
+
+def test_random_configurations_design_the_same_tables_or_fail_alike():
+    # 60 seeded random front-end configurations: both sides either reject the configuration, or agree bit-for-bit on
+    # geometry, window, bank (values and first / last bin), DCT / cosine-iDFT matrix and lifter
+    rng = np.random.default_rng(20260101)
+    ok = 0
+    for _ in range(60):
+        cfg = _random_cfg(rng)
+        try:
+            o = Oracle(cfg)
+        except OracleError:
+            with pytest.raises(CtuError):
+                config_dims(cfg)
+            continue
+        d, od = config_dims(cfg), o.dims
+        assert (d.window, d.wshift, d.wfft, d.nbins, d.nbands, d.row_floats, d.htk_kind) == \
+            (od.window, od.wshift, od.wfft, od.K, od.B, od.D, od.htk_kind), cfg
+        assert np.array_equal(config_table(cfg, "hamming"), o.hamming()), cfg
+        mat, first, last = o.fbank()
+        assert np.array_equal(config_table(cfg, "fbank").reshape(mat.shape), mat), cfg
+        assert np.array_equal(config_table(cfg, "fb_first"), first) and np.array_equal(config_table(cfg, "fb_last"), last), cfg
+        ok += 1
+    assert ok >= 30
