@@ -195,6 +195,8 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
+        if (!o.fb_inld) return "LP analysis without -fb_inld: the autocorrelation of squared band energies spans the whole float range and the normal equations need fp64 throughout (PLP, which compresses with ^0.33, is on the path)";
+        if (o.fea_lporder >= d.B) return "LP order not below the number of bands: the normal equations are singular and the reference's output is rounding noise";
         if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above the in-register limit";
     }
     if (d.kind == ctu::FeaKind::Dctc && d.nfea > MAXC) return "more cepstral coefficients than the kernel accumulates";

@@ -429,18 +429,18 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             float c[NC];
 #pragma unroll
             for (int i = 0; i < NC; i++) c[i] = 0.f;
-            float esum = 0.f;
+            double esum = 0.0;  // -fea_E sums squares of values that may already be powers: beyond the float range on silent frames
             if (o_e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
                 const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : wave * 8) * p.wshift;
                 for (int i = 1 + g; i < p.window; i += 8) {
                     const float x = (float)xr[i];
-                    esum += x * x;
+                    esum += (double)x * x;
                 }
             }
             if (o_e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
                 for (int k = g; k < p.K; k += 8) {
                     const float x = prow2[k];
-                    esum += ((k == 0 || k == p.K - 1) ? 0.5f : 1.0f) * x * x;
+                    esum += ((k == 0 || k == p.K - 1) ? 0.5 : 1.0) * ((double)x * x);
                 }
             }
             for (int sl = 0; sl < p.NS; sl++) {
@@ -484,10 +484,10 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 acc += acc1;
                 float y = acc;
                 if (o_fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
+                if (o_e_mode == 3 && bidx >= 0)  // band energy of the FB output, i.e. after its ^0.33 (src/fea/fea_impl.cc:44-50,68-74)
+                    esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5 : 1.0) * ((double)y * y);
                 // v_log_f32 (log2, ~1 ulp) * ln 2: band energies of int16 speech are far from the denormal range
                 if (FEAT == FEAT_DCTC || (FEAT == FEAT_BANDS && p.band_log)) y = __builtin_amdgcn_logf(y) * 0.69314718056f;
-                if (o_e_mode == 3 && bidx >= 0)  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
-                    esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5f : 1.0f) * acc * acc;
                 if (FEAT == FEAT_BANDS) {
                     float *dst = p.band_to_scratch ? p.logmel : p.rows;
                     const int out_w = p.band_to_scratch ? p.B : p.D;
@@ -502,8 +502,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             STAMP(8);  // filter bank + per-band accumulation
             if (o_e_mode && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
                 float e = 0.f;
-                if (o_e_mode == 1 || o_e_mode == 3) e = __logf(2.0f * lanes8_allreduce_add(esum));
-                else if (o_e_mode == 4) e = __logf(lanes8_allreduce_add(esum));
+                if (o_e_mode == 1 || o_e_mode == 3) e = (float)log(2.0 * lanes8_allreduce_add(esum));
+                else if (o_e_mode == 4) e = (float)log(lanes8_allreduce_add(esum));
                 if (o_e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
             }
             if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {

@@ -125,6 +125,27 @@ __device__ __forceinline__ float lanes8_allreduce_add(float x) {
     return x;
 }
 
+// Row rotation by DPP for 32- and 64-bit values (v_mov_b32_dpp per half), and a wave all-reduce built on it: four
+// rotate-and-add steps inside each row of 16 lanes, then the four row sums through v_readlane.  A shuffle-based
+// butterfly (ds_bpermute) costs an LDS round trip per step; the lattice below runs two reductions per order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// the same 8-lane sum for doubles (energy columns: squares of squares leave the float range on silent frames)
+__device__ __forceinline__ double lanes8_allreduce_add(double x) {
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    x += dpp_mov<0x141>(x);
+    return x;
+}
+
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 

@@ -38,19 +38,6 @@ __device__ __forceinline__ vreal wave_sum_r(vreal x) {
     return x;
 }
 
-// Row rotation by DPP for 32- and 64-bit values (v_mov_b32_dpp per half), and a wave all-reduce built on it: four
-// rotate-and-add steps inside each row of 16 lanes, then the four row sums through v_readlane.  A shuffle-based
-// butterfly (ds_bpermute) costs an LDS round trip per step; the lattice below runs two reductions per order.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ float lane_read(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ double lane_read(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
