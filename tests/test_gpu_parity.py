@@ -413,3 +413,45 @@ def test_random_configurations_match_the_oracle(Engine, seed, fs):
             assert rel_err(g, ref) <= tol or rown <= 2e-5, (rel_err(g, ref), rown, " ".join(cfg))
         ran += 1
     assert ran >= 20, (ran, refused)
+
+
+def test_random_post_processing_chains(Engine):
+    # seeded random delta / stacking / CMS combinations on MFCC and PLP rows
+    rng = np.random.default_rng(21)
+    utts = [sig("CS3")[:40000], synth_utt(77, 16000 * 4 + 123), synth_utt(78, 240 + 160 * 40)]
+    for _ in range(24):
+        base = C2 if rng.random() < 0.7 else C3
+        extra = []
+        mode = rng.choice(["delta", "stack", "none"])
+        wsum = 0
+        if mode == "delta":
+            spec = str(rng.choice(["d", "d_a", "d_a_t"]))
+            ws = [int(rng.integers(1, 7)) for _ in range(3)]
+            wsum = sum(ws[:len(spec.split("_"))])
+            extra += ["-fea_delta", spec, "-d_win", str(ws[0]), "-a_win", str(ws[1]), "-t_win", str(ws[2])]
+        elif mode == "stack":
+            extra += ["-fea_trap", str(int(rng.choice([3, 5, 7, 11, 15])))]
+        if mode != "stack" and rng.random() < 0.6:
+            extra += ["-fea_Z_exp", str(int(rng.integers(100, 3000)))] if rng.random() < 0.5 else ["-fea_Z_block", str(int(rng.integers(60, 3000)))]
+        if rng.random() < 0.5:
+            extra += ["-fea_E", "on"]
+        cfg = list(base) + extra
+        _check(Engine, cfg, utts)
+
+
+def test_random_enhancement_configurations(Engine):
+    rng = np.random.default_rng(31)
+    utts = [sig("CS0")[:30000], synth_utt(79, 16000 * 2 + 5)]
+    for _ in range(16):
+        fs = int(rng.choice([8000, 16000]))
+        w = float(rng.choice([20, 25, 32]))
+        s = float(rng.choice([4, 8, 10, 16]))
+        nr = str(rng.choice(["none", "exten"]))
+        cfg = ["-fs", str(fs), "-format_in", "raw", "-format_out", "raw", "-w", str(w), "-s", str(s), "-preem", str(rng.choice([0, 0.97])),
+               "-remove_dc", str(rng.choice(["on", "off"])), "-nr_mode", nr, "-nr_a", str(rng.choice([1, 2])), "-nr_p", str(rng.choice([0.9, 0.95, 0.98])),
+               "-fea_kind", "none", "-fb_definition", "none"]
+        eng, orc = Engine(cfg), Oracle(cfg)
+        for u, g in zip(utts, eng.enhance(utts)):
+            ref = orc.enhance(u)
+            d = np.abs(g.astype(int) - ref.astype(int))
+            assert g.shape == ref.shape and d.max() <= (2 if nr == "exten" else 1) and d.mean() < 0.35, (d.max(), d.mean(), " ".join(cfg))
