@@ -455,3 +455,25 @@ def test_random_enhancement_configurations(Engine):
             ref = orc.enhance(u)
             d = np.abs(g.astype(int) - ref.astype(int))
             assert g.shape == ref.shape and d.max() <= (2 if nr == "exten" else 1) and d.mean() < 0.35, (d.max(), d.mean(), " ".join(cfg))
+
+
+@pytest.mark.parametrize("extra", [[], ["-nr_mode", "exten"], ["-nr_mode", "exten", "-fea_delta", "d_a", "-fea_Z_exp", "800"],
+                                   ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "perc"]])
+def test_many_ragged_utterances_walk_the_tile_chains(Engine, extra):
+    # 700 utterances of 0..330 frames: more tiles than the 512 workgroups of the stateless chain, more utterances than
+    # workgroups for the exten chain (which hands whole utterances to workgroups); every utterance must come out as if alone
+    rng = np.random.default_rng(5)
+    frames = [int(f) for f in rng.integers(0, 331, 700)]
+    if "-fea_delta" in extra:
+        frames = [f if f == 0 or f >= 4 else 4 for f in frames]
+    utts = [synth_utt(1000 + i, 240 + 160 * f + int(rng.integers(0, 160))) for i, f in enumerate(frames)]
+    cfg = C2 + extra
+    eng, orc = Engine(cfg), Oracle(cfg)
+    want_vad = "-vad_out_mode" in extra
+    got = eng.extract(utts, want_vad=True)[0] if want_vad else eng.extract(utts)
+    assert [g.shape[0] for g in got] == frames
+    worst = 0.0
+    for i in rng.choice(len(utts), 40, replace=False):  # the oracle is the slow side: check a random 40
+        ref = orc.process(utts[i])
+        worst = max(worst, rel_err(got[i], ref))
+    assert worst <= (2e-4 if "exten" in extra else TOL), worst
