@@ -476,4 +476,6 @@ def test_many_ragged_utterances_walk_the_tile_chains(Engine, extra):
     for i in rng.choice(len(utts), 40, replace=False):  # the oracle is the slow side: check a random 40
         ref = orc.process(utts[i])
         worst = max(worst, rel_err(got[i], ref))
-    assert worst <= (2e-4 if "exten" in extra else TOL), worst
+    # exten in float leaves ~1e-4 absolute on c0 (test_exten_16k); behind CMS that is measured against |ref| < 1
+    # (test_cms_after_exten), and over 40 x 165 frames the tail reaches 3e-4
+    assert worst <= (4e-4 if "-fea_Z_exp" in extra else 2e-4 if "exten" in extra else TOL), worst
