@@ -5,10 +5,10 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// VAD module (src/vad/vad.cc, src/vad/vad.h, src/vdet/Burg.h).  Decisions are discontinuous, so this side path
-// computes in double.  Kernel A is frame-parallel (HC2R of the post-NR spectrum with the original phase, Burg
-// lattice, a -> c); kernel B is one thread per utterance and replays the sequential part: cepstral distance to
-// the adaptive background, threshold recurrences, background update, majority ("median") filter.
+// VAD module (src/vad/vad.cc, src/vad/vad.h, src/vdet/Burg.h).  Kernel A (vad_burg_kernel) is frame-parallel: HC2R of
+// the post-NR spectrum with the original phase, Burg lattice, a -> c, in CTU_VAD_REAL arithmetic.  Kernel B
+// (vad_decide_kernel) is one wave per utterance and replays the sequential, discontinuous part in double: cepstral
+// distance to the adaptive background, threshold recurrences, background update, majority ("median") filter.
 // ------------------------------------------------------------------------------------------------
 struct VadParams {
     int K, wfft, window, ncoef;  // ncoef = vad_lpc_coefs (cepdist lpc) or feature vector length (cepdist fea)
@@ -22,11 +22,6 @@ struct VadParams {
 
 // One wave per frame (4 frames per 256-thread workgroup): the frame's samples live in registers, strided over the
 // lanes (sample j = lane + 64 q), reductions are wave shuffles, no workgroup barrier inside the lattice.
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
 
 #ifndef CTU_VAD_REAL
 #define CTU_VAD_REAL float   // arithmetic of the HC2R + Burg kernel.  Its inputs (the front end's spectra) are float; on the
@@ -34,11 +29,6 @@ __device__ __forceinline__ double wave_sum(double x) {
                              // (626 of 1186 on CS3 @ 8 kHz, the count the compiled reference wrote); double costs 1.6x
 #endif
 typedef CTU_VAD_REAL vreal;
-__device__ __forceinline__ vreal wave_sum_r(vreal x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
 
 __device__ __forceinline__ float lane_read(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ double lane_read(double x, int l) {
