@@ -20,9 +20,9 @@ struct VadParams {
     int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
 };
 
-// One wave per frame (4 frames per 256-thread workgroup): the frame's samples live in registers, strided over the
-// lanes (sample j = lane + 64 q), reductions are wave shuffles, no workgroup barrier inside the lattice.
-
+// vad_burg_kernel: one wave per frame (4 waves per workgroup, persistent): the frame's samples live in registers,
+// strided over the lanes (sample j = lane + 64 q); reductions are DPP row rotations + v_readlane (wave_sum_fast), no
+// workgroup barrier inside the lattice.
 #ifndef CTU_VAD_REAL
 #define CTU_VAD_REAL float   // arithmetic of the HC2R + Burg kernel.  Its inputs (the front end's spectra) are float; on the
                              // reference recordings float and double give the same decisions, frame for frame, as the oracle
