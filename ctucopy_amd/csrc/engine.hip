@@ -941,8 +941,13 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const size_t shm = ((size_t)R * d.Dbase + (size_t)(d.post_stack ? 0 : d.post_order) * R * pp.fea_c) * sizeof(float);
             if ((size_t)R * d.Dbase > 256 * 12) throw std::runtime_error("delta tile larger than the prefetch registers");
             const int pgrid = std::min(pl->n_trap_chunks, e->n_cu * 8);
-            hipLaunchKernelGGL(post_kernel, dim3(pgrid), dim3(256), shm, s, pl->base_rows.p, d_rows,
-                               pl->utt_info.p, pl->trap_chunks.p, pl->n_trap_chunks, pp);
+            const bool std39 = !d.post_stack && d.post_order == 2 && pp.fea_c == 13 && d.Dbase == 13 && d.D == 39 && pp.w[0] == 2 && pp.w[1] == 2;
+            if (std39)
+                hipLaunchKernelGGL(post_kernel<true>, dim3(pgrid), dim3(256), shm, s, pl->base_rows.p, d_rows,
+                                   pl->utt_info.p, pl->trap_chunks.p, pl->n_trap_chunks, pp);
+            else
+                hipLaunchKernelGGL(post_kernel<false>, dim3(pgrid), dim3(256), shm, s, pl->base_rows.p, d_rows,
+                                   pl->utt_info.p, pl->trap_chunks.p, pl->n_trap_chunks, pp);
             HIP_TRY(hipGetLastError());
         }
         if (d.cms) {

@@ -26,13 +26,17 @@ struct PostParams {
     float inv_den[3];
 };
 
+template <bool STD>  // STD: the MFCC_0_D_A layout (13 -> 39 floats, windows 2 / 2) with every size a constant
 __global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ base, float *__restrict__ rows,
                                                    const int4 *__restrict__ utt_info, const int *__restrict__ chunks,
                                                    const int n_chunks, const PostParams pp) {
     extern __shared__ float psm[];
-    constexpr int PF = 12;  // prefetch registers per thread; the host keeps R * Dbase <= 256 * PF
-    const int fc = pp.fea_c, Db = pp.Dbase, D = pp.D;
-    const int H = pp.stack ? pp.w[0] : pp.w[0] + (pp.order > 1 ? pp.w[1] : 0) + (pp.order > 2 ? pp.w[2] : 0);
+    constexpr int PF = STD ? 4 : 12;  // prefetch registers per thread; the host keeps R * Dbase <= 256 * PF
+    const int fc = STD ? 13 : pp.fea_c, Db = STD ? 13 : pp.Dbase, D = STD ? 39 : pp.D;
+    const int order_ = STD ? 2 : pp.order;
+    const bool stack_ = STD ? false : pp.stack != 0;
+    const int wv[3] = {STD ? 2 : pp.w[0], STD ? 2 : pp.w[1], STD ? 0 : pp.w[2]};
+    const int H = stack_ ? wv[0] : wv[0] + (order_ > 1 ? wv[1] : 0) + (order_ > 2 ? wv[2] : 0);
     const int R = 64 + 2 * H;
     float *x0 = psm;                        // [R][Db]   base rows (E column included)
     float *lv = psm + (size_t)R * Db;       // levels 1..order: [R][fc] each
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ bas
             issue(mn, r);
         }
         auto rowof = [&](int f) { return min(max(f, 0), T - 1) - tlo; };
-        if (pp.stack) {
-            const int w = pp.w[0], L = 2 * w + 1, xs = fc * L;
+        if (stack_) {
+            const int w = wv[0], L = 2 * w + 1, xs = fc * L;
             const float invL = 1.0f / (float)L;
             int tt = tt_first, k = k_first;
             for (int e = threadIdx.x; e < nout * D; e += 256, tt += dqD, k += drD) {
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ bas
             int hk = H;
             const float *prev = x0;
             int pstride = Db;
-            for (int k = 0; k < pp.order; k++) {
-                const int w = pp.w[k];
+            for (int k = 0; k < order_; k++) {
+                const int w = wv[k];
                 hk -= w;  // halo this level still needs for the stages after it
                 float *cur = lv + (size_t)k * R * fc;
                 const int flo = max(t0 - hk, 0), fhi = min(t0 + 63 + hk, T - 1);
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void post_kernel(const float *__restrict__ bas
                 prev = cur;
                 pstride = fc;
             }
-            const int xs = fc * (pp.order + 1);
+            const int xs = fc * (order_ + 1);
             int tt = tt_first, k = k_first;
             for (int e = threadIdx.x; e < nout * D; e += 256, tt += dqD, k += drD) {
                 if (k >= D) { k -= D; tt++; }
