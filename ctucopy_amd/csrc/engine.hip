@@ -1144,7 +1144,7 @@ int ctu_engine_run_signal(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pc
         sp.inv_n = 1.0f / (float)d.wfft;
         sp.corr = d.ola_corr;
         if (pl->total_frames > 0) {
-            const int g = (int)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 8);
+            const int g = (int)std::min<int64_t>((pl->total_frames + 7) / 8, (int64_t)e->n_cu * 8);
             hipLaunchKernelGGL(synth_kernel, dim3(g), dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->ybuf.p, (long long)pl->total_frames, sp);
             HIP_TRY(hipGetLastError());
         }

@@ -25,21 +25,23 @@ struct SynthParams {
 __global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr,
                                                     float *__restrict__ ybuf, long long total_frames, const SynthParams sp) {
     __shared__ float2 root[512];          // e^{+2 pi i m / 512}
-    __shared__ float2 bufs[4][2][260];
+    __shared__ float2 bufs[8][2][260];  // two frames per wave (32 lanes each): the four dependent LDS passes of a frame are latency-bound
     for (int m = threadIdx.x; m < 512; m += 256) {
         float sn, cs;
         sincospif((float)m / 256.0f, &sn, &cs);
         root[m] = make_float2(cs, sn);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 31, half = (threadIdx.x >> 5) & 1, wave = threadIdx.x >> 6;
     const int M = sp.wfft / 2;            // 256 or 128
     const int rs = 512 / sp.wfft;         // stride of the N-th roots in the table
-    float2 *A = bufs[wave][0], *Bf = bufs[wave][1];
-    for (long long f = (long long)blockIdx.x * 4 + wave; f < total_frames; f += (long long)gridDim.x * 4) {
+    float2 *A = bufs[wave * 2 + half][0], *Bf = bufs[wave * 2 + half][1];
+    for (long long f0 = ((long long)blockIdx.x * 4 + wave) * 2; f0 < total_frames; f0 += (long long)gridDim.x * 8) {
+        const bool live = f0 + half < total_frames;   // an odd tail frame: the idle half recomputes it, stores nothing
+        const long long f = live ? f0 + half : f0;
         const float2 *xr = xri + f * sp.K;
         const float *pn = pnr + f * sp.K;
-        for (int k = lane; k <= M; k += 64) {
+        for (int k = lane; k <= M; k += 32) {
             float2 v;
             if (k == 0 || k == M) v = make_float2(pn[k] * sp.inv_n, 0.f);
             else {
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ x
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int k = lane; k < M; k += 64) {
+        for (int k = lane; k < M; k += 32) {
             const float2 a = A[k], b = A[M - k];
             const float2 sm = make_float2(a.x + b.x, a.y - b.y);      // X[k] + conj(X[M-k])
             const float2 df = make_float2(a.x - b.x, a.y + b.y);      // X[k] - conj(X[M-k])
@@ -66,13 +68,13 @@ __global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ x
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float2 *src = Bf, *dst = A;
-        int Ns = 1;
+        int Ns = 1, lg = 0;      // Ns = 1 << lg: sub-transform length so far (powers of two: masks and shifts, no division)
         const int mr = 512 / M;  // stride of the M-th roots in the table
         while (Ns * 4 <= M) {
             const int q4 = M / 4;
-            for (int j = lane; j < q4; j += 64) {
-                const int kk = j % Ns;
-                const int tstep = kk * (M / (4 * Ns)) * mr;  // index of e^{2 pi i kk / (4 Ns)} in the table
+            for (int j = lane; j < q4; j += 32) {
+                const int kk = j & (Ns - 1);
+                const int tstep = (kk * (q4 * mr)) >> lg;    // index of e^{2 pi i kk / (4 Ns)} in the table
                 const float2 v0 = src[j];
                 float2 v1 = src[j + q4], v2 = src[j + 2 * q4], v3 = src[j + 3 * q4];
                 v1 = cmul(v1, root[(tstep) & 511]);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ x
                 // inverse radix-4 butterfly (W4 = +i)
                 const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
                 const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
-                const int base = (j / Ns) * Ns * 4 + kk;
+                const int base = ((j >> lg) << (lg + 2)) + kk;
                 dst[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
                 dst[base + Ns] = make_float2(d02.x - d13.y, d02.y + d13.x);      // d02 + i d13
                 dst[base + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
@@ -92,14 +94,15 @@ __global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ x
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float2 *tmp = src; src = dst; dst = tmp;
             Ns *= 4;
+            lg += 2;
         }
         if (Ns < M) {  // one radix-2 pass (M = 128)
             const int h = M / 2;
-            for (int j = lane; j < h; j += 64) {
-                const int kk = j % Ns;
+            for (int j = lane; j < h; j += 32) {
+                const int kk = j & (Ns - 1);
                 const float2 v0 = src[j];
-                const float2 v1 = cmul(src[j + h], root[(kk * (M / (2 * Ns)) * mr) & 511]);
-                const int base = (j / Ns) * Ns * 2 + kk;
+                const float2 v1 = cmul(src[j + h], root[((kk * (h * mr)) >> lg) & 511]);
+                const int base = ((j >> lg) << (lg + 1)) + kk;
                 dst[base] = make_float2(v0.x + v1.x, v0.y + v1.y);
                 dst[base + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
             }
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void synth_kernel(const float2 *__restrict__ x
             float2 *tmp = src; src = dst; dst = tmp;
         }
         float2 *yo = reinterpret_cast<float2 *>(ybuf + f * sp.window);  // window is even (checked on the host)
-        for (int n = lane; 2 * n < sp.window; n += 64) yo[n] = src[n];
+        if (live)
+            for (int n = lane; 2 * n < sp.window; n += 32) yo[n] = src[n];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
