@@ -129,15 +129,29 @@ __global__ __launch_bounds__(256) void ola_kernel(const float *__restrict__ ybuf
     const int T = ui.z, w = sp.window, s = sp.wshift;
     const long long nout = (long long)T * s + (w - s);
     int16_t *o = out + sample_off[u];
-    for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < nout; n += (long long)gridDim.x * 256) {
-        long long t0 = (n - w + s) / s;   // ceil((n - w + 1) / s) for n - w + 1 > 0
-        if (n - w + 1 <= 0) t0 = 0;
-        long long t1 = n / s;
-        if (t1 > T - 1) t1 = T - 1;
-        double acc = 0.0;
-        for (long long t = t0; t <= t1; t++) acc += (double)ybuf[(ro + t) * w + (n - t * s)];
-        const int value = (int)floor(acc / sp.corr);
-        o[n] = fabsf((float)value) > 32767.f ? (value < 0 ? -32767 : 32767) : (int16_t)value;
+    // four samples per thread and step: their loads are independent, which is what keeps enough bytes in flight
+    const int stride = gridDim.x * 256;
+    for (long long n0 = (long long)blockIdx.x * 256 + threadIdx.x; n0 < nout; n0 += 4LL * stride) {
+        double acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n = (int)(n0 + (long long)q * stride);  // an utterance stays far below 2^31 samples
+            acc[q] = 0.0;
+            if (n < nout) {
+                int t0 = n - w + 1 <= 0 ? 0 : (n - w + s) / s;  // ceil((n - w + 1) / s)
+                int t1 = n / s;
+                if (t1 > T - 1) t1 = T - 1;
+                for (int t = t0; t <= t1; t++) acc[q] += (double)ybuf[(ro + t) * w + (n - t * s)];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long n = n0 + (long long)q * stride;
+            if (n < nout) {
+                const int value = (int)floor(acc[q] / sp.corr);
+                o[n] = fabsf((float)value) > 32767.f ? (value < 0 ? -32767 : 32767) : (int16_t)value;
+            }
+        }
     }
 }
 
