@@ -9,7 +9,7 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "libctu_engine.so")
 CLI = os.path.join(ROOT, "bin", "ctucopy")
 
-ENGINE_SRCS = ["engine.hip", "opts.cc", "design.cc"]
+ENGINE_SRCS = ["engine.hip", "opts.cc", "design.cc", "synth.cc"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -25,10 +25,10 @@ def _deps(dirpath):
 
 
 def build_engine(force=False, verbose=False):
-    deps = _deps(CSRC) + [os.path.join(ROOT, "include", "ctu_engine.h")]
+    deps = _deps(CSRC) + [os.path.join(ROOT, "include", h) for h in ("ctu_engine.h", "ctu_synth.h")]
     if force or _newer(LIB, deps):
         # -fno-slp-vectorize: packed f32 VALU (v_pk_*) plus the moves it needs is slower than scalar f32 on gfx950
-        cmd = [HIPCC, "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+        cmd = [HIPCC, "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pthread",
                *[os.path.join(CSRC, s) for s in ENGINE_SRCS], "-o", LIB]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

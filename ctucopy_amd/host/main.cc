@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "g711.h"
 #include "ctu_engine.h"
 #include "opts.h"
 
@@ -37,29 +38,6 @@ struct Item {
 };
 
 // ---------------------------------------------------------------- decoders
-// G.711 expansion exactly as the reference computes it (src/io/amulaw.h:20-53): chord/step -> magnitude,
-// then "2x amplification" in 16-bit wrap-around arithmetic.
-int16_t g711_to_linear(uint8_t code, bool alaw) {
-    const int a = (int)(int8_t)code;  // the reference works on a (signed) char
-    const int sgn = (~(a >> 7)) & 1;
-    int mag;
-    if (!alaw) {
-        const int chord = (~(a >> 4)) & 7, step = (~a) & 0xf;
-        mag = (((2 * step) + 33) << chord) - 33;
-    } else {
-        int chord = ((a ^ 0x55) >> 4) & 7;
-        const int step = (a ^ 0x55) & 0xf;
-        mag = (step << 1) + 1;
-        if (chord > 0) mag += 32;
-        else chord = 1;
-        mag <<= chord;
-    }
-    int out = ((1 - 2 * sgn) * mag) & 0xffff;
-    out = (out << 2) & 0xffff;
-    if (out & 0x8000) out -= 65536;
-    return (int16_t)out;
-}
-
 std::vector<uint8_t> read_all(const std::string &path, const char *err) {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) throw Fatal(err);

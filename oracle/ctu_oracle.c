@@ -973,6 +973,71 @@ void ctuo_burg_cepstrum(const double *x, int np, int nc, double *a_out, double *
     free(ef); free(eb); free(efo); free(ebo); free(a); free(aa);
 }
 
+/* ------------------------------------------------------------------ CepstralDetector<BurgCepstrumEstimator>
+ * src/vdet/CepstralDet.h:92-217 (the detector hwss / fwss / 2fwss create per file, src/nr/nr.cc:263-276).
+ * Pinned bit for bit against the reference's own header compiled in place (tests/test_oracle_cepdet_ref.py). */
+struct ctuo_cepdet {
+    int np, ninit, nc;
+    double p, q;
+    double *han, *x, *c0, *ci;
+    double dMean, dMean2, dVar, threshold, last_dist;
+    int nseg;
+};
+
+ctuo_cepdet_t *ctuo_cepdet_new(int npoints, int ninit, int ncoefs, double p, double q) {
+    ctuo_cepdet_t *d = calloc(1, sizeof *d);
+    d->np = npoints; d->ninit = ninit; d->nc = ncoefs; d->p = p; d->q = q;
+    d->han = malloc(sizeof(double) * npoints);
+    d->x = malloc(sizeof(double) * npoints);
+    d->c0 = calloc(ncoefs, sizeof(double));
+    d->ci = calloc(ncoefs, sizeof(double));
+    double m = 2 * 3.141592653 / npoints;                       /* CepstralDet.h:133 (this literal) */
+    for (int i = 0; i < npoints; i++) d->han[i] = 0.5 * (1 - cos(m * i));
+    return d;
+}
+
+void ctuo_cepdet_free(ctuo_cepdet_t *d) {
+    if (!d) return;
+    free(d->han); free(d->x); free(d->c0); free(d->ci); free(d);
+}
+
+static double cepdet_distance(const ctuo_cepdet_t *d) {      /* CepstralDet.h:64-80: the first coefficient is skipped */
+    double sum = 0.0;
+    for (int i = 1; i < d->nc; i++) sum += (d->ci[i] - d->c0[i]) * (d->ci[i] - d->c0[i]);
+    return 4.3429 * sqrt(2 * sum);
+}
+
+int ctuo_cepdet_process(ctuo_cepdet_t *d, const double *frame) {  /* CepstralDet.h:140-194 */
+    int result = 0;
+    for (int i = 0; i < d->np; i++) d->x[i] = d->han[i] * frame[i];
+    ctuo_burg_cepstrum(d->x, d->np, d->nc, NULL, d->ci, NULL);
+    if (d->nseg == 0) {
+        for (int i = 0; i < d->nc; i++) d->c0[i] = d->ci[i];
+    } else if (d->nseg == 1) {
+        for (int i = 0; i < d->nc; i++) d->c0[i] = (d->c0[i] + d->ci[i]) / 2.0;
+        double dist = cepdet_distance(d);
+        d->last_dist = dist;
+        d->dMean = dist;
+        d->dMean2 = dist * dist;
+        d->threshold = d->dMean;
+    } else {
+        double dist = cepdet_distance(d);
+        d->last_dist = dist;
+        result = (d->nseg > d->ninit && dist >= d->threshold);
+        if (!result) {
+            for (int i = 0; i < d->nc; i++) d->c0[i] = d->p * d->c0[i] + (1 - d->p) * d->ci[i];
+            d->dMean = d->q * d->dMean + (1 - d->q) * dist;
+            d->dMean2 = d->q * d->dMean2 + (1 - d->q) * dist * dist;
+            d->dVar = d->dMean2 - d->dMean * d->dMean;
+            d->threshold = d->dMean + 2.0 * sqrt(d->dVar);
+        }
+    }
+    ++d->nseg;
+    return result;
+}
+
+double ctuo_cepdet_last_distance(const ctuo_cepdet_t *d) { return d->last_dist; }
+
 /* ------------------------------------------------------------------ phase (src/io/in.cc:187-200) */
 static double c_ph(double re, double im) {
     static const double hpi = 1.57079632679490;

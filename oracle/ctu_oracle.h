@@ -87,6 +87,14 @@ const double *ctuo_last_fbank(const ctuo_t *);  /* B values after FB (before log
 /* Stand-alone Burg lattice + a->c, restating src/vdet/Burg.h:49-152 (for the pin test). */
 void ctuo_burg_cepstrum(const double *x, int npoints, int ncoefs, double *a_out, double *c_out, double *alpha_out);
 
+/* Stand-alone CepstralDetector<BurgCepstrumEstimator>, restating src/vdet/CepstralDet.h:92-217 (for the pin test
+ * and for the hwss / fwss / 2fwss noise-reduction modes, src/nr/nr.cc:263-295). */
+typedef struct ctuo_cepdet ctuo_cepdet_t;
+ctuo_cepdet_t *ctuo_cepdet_new(int npoints, int ninit, int ncoefs, double p, double q);
+int ctuo_cepdet_process(ctuo_cepdet_t *, const double *frame);   /* 1 = speech */
+double ctuo_cepdet_last_distance(const ctuo_cepdet_t *);
+void ctuo_cepdet_free(ctuo_cepdet_t *);
+
 #ifdef __cplusplus
 }
 #endif

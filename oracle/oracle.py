@@ -64,6 +64,12 @@ def lib():
         L.ctuo_last_fbank.argtypes = [ctypes.c_void_p]
         L.ctuo_burg_cepstrum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p]
+        L.ctuo_cepdet_new.restype = ctypes.c_void_p
+        L.ctuo_cepdet_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        L.ctuo_cepdet_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.ctuo_cepdet_last_distance.restype = ctypes.c_double
+        L.ctuo_cepdet_last_distance.argtypes = [ctypes.c_void_p]
+        L.ctuo_cepdet_free.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -161,6 +167,27 @@ def burg_cepstrum(x, ncoefs):
     alpha = ctypes.c_double()
     lib().ctuo_burg_cepstrum(x.ctypes.data, x.size, ncoefs, a.ctypes.data, c.ctypes.data, ctypes.byref(alpha))
     return a, c, alpha.value
+
+
+class CepstralDetector:
+    """CepstralDetector<BurgCepstrumEstimator> of src/vdet/CepstralDet.h:92-217 (one instance per file in hwss / fwss)."""
+
+    def __init__(self, npoints, ninit=40, ncoefs=10, p=0.8, q=0.97):
+        self._h = lib().ctuo_cepdet_new(npoints, ninit, ncoefs, p, q)
+        self.npoints = npoints
+
+    def process(self, frame):
+        f = np.ascontiguousarray(frame, dtype=np.float64)
+        assert f.size == self.npoints
+        return int(lib().ctuo_cepdet_process(self._h, f.ctypes.data))
+
+    def last_distance(self):
+        return float(lib().ctuo_cepdet_last_distance(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ctuo_cepdet_free(self._h)
+            self._h = None
 
 
 def htk_bytes(rows, period, kind, big_endian=False):

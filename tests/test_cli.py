@@ -138,6 +138,12 @@ def test_wave_and_alaw_inputs(tmp_path):
     outv = ((1 - 2 * sgn) * mag) & 0xFFFF
     outv = (outv << 2) & 0xFFFF
     table = np.where(outv & 0x8000, outv - 65536, outv).astype(np.int16)
+    ref_so = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libref_amulaw.so")
+    if os.path.exists(ref_so):  # the reference's own expander compiled in place (tests/test_host_decoders.py)
+        import ctypes
+        rt = np.zeros(256, dtype=np.int16)
+        ctypes.CDLL(ref_so).ref_amulaw_table(1, rt.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(rt, table)
     rng = np.random.default_rng(0)
     raw = rng.integers(0, 256, size=24000, dtype=np.uint8)
     (tmp_path / "x.al").write_bytes(raw.tobytes())
