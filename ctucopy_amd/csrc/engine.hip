@@ -21,6 +21,8 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <queue>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -86,7 +88,9 @@ struct ctu_engine {
     int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
     DevBuf<float> lanec, ftab, trapG;
     DevBuf<int> itab;
-    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
+    bool per_wave = false;  // chains per wave (state along an utterance lives in a wave's registers)
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -96,6 +100,7 @@ struct ctu_engine {
     DevBuf<int> d_col_of_slot, d_slot_of_col, d_spk;
     DevBuf<double> d_stat_a, d_stat_b;
     DevBuf<unsigned long long> stamps;
+    std::set<const void *> attr_done;  // kernels whose dynamic-LDS limit has been raised on this engine's device
     bool do_vad = false;
     VadParams vp;
 };
@@ -212,10 +217,22 @@ struct Phase2Tables {
     std::vector<float> ft;   // LDS image followed by the lifter
     std::vector<int> it;     // slot_chunk[NS+1] | row_slot[nfea]
     std::vector<int> cells, slot_chunk;
-    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    bool md = false;  // lane map of the MFMA tail: lane = frame + 8 h + 16 kk, group = kk + 4 h
 };
 
+// The DCT tail runs on the matrix cores for the plain cepstral chains (what launch_vx instantiates with MD).
+#ifndef CTU_MD
+#define CTU_MD 1
+#endif
+bool md_eligible(const ctu::Design &d) {
+    const ctu::Opts &o = d.o;
+    return CTU_MD && d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !o.do_vad() &&
+           !d.signal_out;
+}
+
 void build_phase2(const ctu::Design &d, Phase2Tables &t) {
+    t.md = md_eligible(d);
     // ---- phase-2 tables.  Bands are dealt to (slot, group) cells: sorted by width, eight per slot, so that the
     // eight lanes of a frame walk bands of similar width in lock step.  A band is cut into 4-bin chunks whose
     // bin range stays inside [0,K); weights outside the band's own [first,last] are zero.
@@ -269,12 +286,19 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
         auto cost = [&](const std::vector<int> &pm, const std::vector<int> &ld) {
             int c = 0, a[8];
             for (int g = 0; g < 8; g++) a[g] = a_of(pm[g], ld[g]);
-            const int fo[4] = {0, 1, 2, 3}, lo[4] = {1, 0, 0, 1};  // frame offset, uses groups 0-3 (1) or 4-7 (0)
-            int unit[16], n = 0;
-            for (int q = 0; q < 4; q++)
-                for (int g = lo[q] ? 0 : 4; g < (lo[q] ? 4 : 8); g++) unit[n++] = a[g] < -500 ? -1 - n : ((a[g] + fo[q]) % 16 + 16) % 16;
-            for (int i = 0; i < 16; i++)
-                for (int j = i + 1; j < 16; j++) c += (unit[i] >= 0 && unit[i] == unit[j]);
+            // a ds_read_b128 is served in four groups of 16 lanes: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
+            static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                           {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+            for (int q = 0; q < 4; q++) {
+                int unit[16];
+                for (int i = 0; i < 16; i++) {
+                    const int lane = grp[q & 1][i] + 32 * (q >> 1);
+                    const int f8 = t.md ? (lane & 7) : (lane >> 3), g = t.md ? (((lane >> 3) & 1) * 4 + (lane >> 4)) : (lane & 7);
+                    unit[i] = a[g] < -500 ? -1 - i : ((a[g] + f8) % 16 + 16) % 16;  // rows are 65 units apart
+                }
+                for (int i = 0; i < 16; i++)
+                    for (int j = i + 1; j < 16; j++) c += (unit[i] >= 0 && unit[i] == unit[j]);
+            }
             return c;
         };
         {
@@ -343,8 +367,22 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
     t.ck_off = (int)ft.size();
     push_ints(cell);
     t.cf_off = (int)ft.size();
-    ft.insert(ft.end(), cf.begin(), cf.end());
+    if (!t.md) ft.insert(ft.end(), cf.begin(), cf.end());  // the MFMA tail reads the am table below instead
     while (ft.size() & 3) ft.push_back(0.f);
+    if (t.md) {
+        // A operands of the DCT MFMAs: for slot sl and half h, lane m + 16 kk holds row m of the folded DCT table at the
+        // band of cell (sl, group kk + 4 h); zero for idle cells and for rows >= the number of output slots
+        t.am_off = (int)ft.size();
+        for (int sl = 0; sl < NS; sl++)
+            for (int h = 0; h < 2; h++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int m = lane & 15, g = (lane >> 4) + 4 * h;
+                    const int b = cell[(sl * 8 + g) * 2 + 1];
+                    float v = 0.f;
+                    if (b >= 0 && m < t.ncoef_out && coef_of_slot[m] >= 0) v = (float)(*coef_tab)[(size_t)coef_of_slot[m] * B + b];
+                    ft.push_back(v);
+                }
+    }
     t.tab_floats = (int)ft.size();
     t.NS = NS;
     t.CW = CW;
@@ -428,6 +466,8 @@ void build_tables(ctu_engine *e) {
     e->ncoef_out = t.ncoef_out;
     e->ck_off = t.ck_off;
     e->cf_off = t.cf_off;
+    e->am_off = t.am_off;
+    e->md = t.md;
     e->tab_floats = t.tab_floats;
     e->NS = t.NS;
     e->CW = t.CW;
@@ -452,49 +492,51 @@ void build_tables(ctu_engine *e) {
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
 }
 
-template <int NZ, int MODE, bool VX, int GEN>
-void launch_nz(int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
-#define LAUNCH(F, NCW)                                                                                 \
-    {                                                                                                  \
-        static bool attr_set = false;                                                                  \
-        if (!attr_set) {                                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, F, MODE, VX, NCW, GEN>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
-            attr_set = true;                                                                           \
-        }                                                                                              \
-        hipLaunchKernelGGL((frontend_kernel<NZ, F, MODE, VX, NCW, GEN>), grid, dim3(WG), shm, s, kp);   \
+// One front-end launch.  The 160 KiB dynamic-LDS attribute is set once per engine (= per device) and instantiation.
+template <class K>
+void launch_fe(ctu_engine *e, K kern, dim3 grid, hipStream_t s, const KParams &kp) {
+    const void *fp = reinterpret_cast<const void *>(kern);
+    if (!e->attr_done.count(fp)) {
+        HIP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e->attr_done.insert(fp);
     }
+    hipLaunchKernelGGL(kern, grid, dim3(WG), e->lds_bytes, s, kp);
+}
+
+template <int NZ, int MODE, bool VX, int GEN>
+void launch_nz(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const bool wide = kp.CW != 16;  // coefficient rows of MAXC entries (more than 16 cepstra / LP lags)
-    if (feat == FEAT_BANDS) LAUNCH(FEAT_BANDS, 16)
-    else if (feat == FEAT_DCTC && !wide) LAUNCH(FEAT_DCTC, 16)
-    else if (feat == FEAT_DCTC) LAUNCH(FEAT_DCTC, MAXC)
-    else if (!wide) LAUNCH(FEAT_LP, 16)
-    else LAUNCH(FEAT_LP, MAXC)
-#undef LAUNCH
+    const int feat = e->feat;
+    if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, VX, 16, GEN>, grid, s, kp);
+    else if (feat == FEAT_DCTC && !wide) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, VX, 16, GEN>, grid, s, kp);
+    else if (feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, VX, MAXC, GEN>, grid, s, kp);
+    else if (!wide) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, VX, 16, GEN>, grid, s, kp);
+    else launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, VX, MAXC, GEN>, grid, s, kp);
 }
 
 template <int NZ, int MODE>
-void launch_vx(bool vx, int feat, dim3 grid, hipStream_t s, const KParams &kp, size_t shm) {
+void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     // Specialised instantiations (see GEN in frontend_kernel.h): the plain chain, plain + intensity-loudness law for the
-    // 16-coefficient LP path (PLP), plain + exten for 16-coefficient DCT / band outputs.  Everything else, and every
-    // run with the VAD export, reads its flags at run time.
+    // 16-coefficient LP path (PLP), plain + exten for 16-coefficient DCT / band outputs; the cepstral ones of these run
+    // their DCT tail on the matrix cores (MD, tables laid out for it by build_phase2).  Everything else, and every run
+    // with the VAD export, reads its flags at run time.
+    const bool vx = kp.vad_export != 0;
+    const int feat = e->feat;
     const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
     const bool narrow = kp.CW == 16;
-    if (vx) launch_nz<NZ, MODE, true, GEN_FULL>(feat, grid, s, kp, shm);
-    else if (base && !kp.fb_inld && !kp.nr_exten) launch_nz<NZ, MODE, false, GEN_PLAIN>(feat, grid, s, kp, shm);
-    else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP && kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) {
-        // the PLP preset exactly: order and number of cepstra fixed at compile time (LPO)
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12>), grid, dim3(WG), shm, s, kp);
+    if (e->md) {
+        if (!(base && !kp.fb_inld && feat == FEAT_DCTC && narrow)) throw std::runtime_error("internal: MD tables without the MD instantiation");
+        if (kp.nr_exten) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_EXTEN, 0, true>, grid, s, kp);
+        else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true>, grid, s, kp);
     }
-    else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP) launch_nz<NZ, MODE, false, GEN_INLD>(FEAT_LP, grid, s, kp, shm);
-    else if (base && !kp.fb_inld && kp.nr_exten && narrow && feat != FEAT_LP) launch_nz<NZ, MODE, false, GEN_EXTEN>(feat, grid, s, kp, shm);
-    else launch_nz<NZ, MODE, false, GEN_FULL>(feat, grid, s, kp, shm);
+    else if (vx) launch_nz<NZ, MODE, true, GEN_FULL>(e, grid, s, kp);
+    else if (base && !kp.fb_inld && !kp.nr_exten) launch_nz<NZ, MODE, false, GEN_PLAIN>(e, grid, s, kp);
+    else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP && kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa)
+        // the PLP preset exactly: order and number of cepstra fixed at compile time (LPO)
+        launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12>, grid, s, kp);
+    else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD>, grid, s, kp);
+    else if (base && !kp.fb_inld && kp.nr_exten && narrow && feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_EXTEN>, grid, s, kp);
+    else launch_nz<NZ, MODE, false, GEN_FULL>(e, grid, s, kp);
 }
 
 std::vector<std::string> to_args(int argc, const char *const *argv) {
@@ -613,6 +655,7 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             const ctu::Opts &o = e->design->o;
             const ctu::Design &d = *e->design;
             e->do_vad = o.do_vad();
+            e->per_wave = o.nr_mode == "exten";  // state along an utterance: a wave per chain
             VadParams &vp = e->vp;
             std::memset(&vp, 0, sizeof vp);
             vp.K = d.K; vp.wfft = d.wfft; vp.window = d.window;
@@ -728,17 +771,29 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     // per-utterance recurrence (exten) a workgroup takes whole utterances, tile after tile.
     std::vector<int> wg_first;
     const int max_wg = e->n_cu * ((CTU_LB >= 4 && e->lds_bytes <= (size_t)LDS_2WG) ? 2 : 1);
-    if (d.o.nr_mode == "exten") {
+    if (e->per_wave) {
+        // chains per wave: whole utterances, longest first onto the least loaded chain (LPT), tile after tile
         std::vector<int> live;  // utterances that have at least one frame
         for (int i = 0; i < n_utt; i++)
             if (uts[i + 1] > uts[i]) live.push_back(i);
-        const int G = std::max(1, std::min<int>((int)live.size(), max_wg));
-        wg_first.assign(G, -1);
-        for (size_t k = 0; k < live.size(); k++) {
-            const int u = live[k];
+        std::stable_sort(live.begin(), live.end(), [&](int a, int b) { return pl->frames[a] > pl->frames[b]; });
+        const int C = std::max(1, std::min<int>((int)live.size(), max_wg * NWAVE));
+        const int G = (C + NWAVE - 1) / NWAVE;
+        wg_first.assign((size_t)G * NWAVE, -1);
+        std::vector<int> tail(C, -1);  // last tile of each chain so far
+        std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<std::pair<int64_t, int>>> load;
+        // chain c lives in wave c / G of workgroup c % G: the chains of one workgroup are spread over the length ranks
+        for (int c = 0; c < C; c++) load.push({0, c});
+        for (int u : live) {
+            const auto top = load.top();
+            load.pop();
+            const int c = top.second, slot = (c % G) * NWAVE + c / G;
             for (int t = uts[u]; t + 1 < uts[u + 1]; t++) tiles[t].next = t + 1;
-            tiles[uts[u + 1] - 1].next = (k + G < live.size()) ? uts[live[k + G]] : -1;
-            if ((int)k < G) wg_first[k] = uts[u];
+            tiles[uts[u + 1] - 1].next = -1;
+            if (tail[c] < 0) wg_first[slot] = uts[u];
+            else tiles[tail[c]].next = uts[u];
+            tail[c] = uts[u + 1] - 1;
+            load.push({top.first + pl->frames[u], c});
         }
         pl->grid = G;
     } else {
@@ -856,8 +911,13 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.lifter_on = d.o.fea_lifter > 1;
         kp.nr_exten = d.o.nr_mode == "exten";
         kp.nr_p = (float)d.o.nr_p;
+        kp.nr_p_d = d.o.nr_p;
         kp.nr_a = (float)d.o.nr_a;
+        kp.per_wave = e->per_wave ? 1 : 0;
+        kp.am_off = e->am_off;
+#ifdef CTU_DIAG  // phase ablation (1 = phase 1 only, 2 = phase 2 only): diagnostic builds only
         kp.dbg = getenv("CTU_DEBUG_MODE") ? atoi(getenv("CTU_DEBUG_MODE")) : 0;
+#endif
         const int grid = pl->grid;
 #if CTU_STAMP
         if (e->stamps.n < (size_t)grid * NWAVE * 16) e->stamps.alloc((size_t)grid * NWAVE * 16);
@@ -866,8 +926,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #endif
         HIP_TRY(hipEventRecord(e->ev0, s));
         switch (e->nz) {
-            case 13: e->mode ? launch_vx<13, 1>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_vx<13, 0>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes); break;
-            default: e->mode ? launch_vx<16, 1>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes) : launch_vx<16, 0>(kp.vad_export, e->feat, dim3(grid), s, kp, e->lds_bytes); break;
+            case 13: e->mode ? launch_vx<13, 1>(e, dim3(grid), s, kp) : launch_vx<13, 0>(e, dim3(grid), s, kp); break;
+            default: e->mode ? launch_vx<16, 1>(e, dim3(grid), s, kp) : launch_vx<16, 0>(e, dim3(grid), s, kp); break;
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

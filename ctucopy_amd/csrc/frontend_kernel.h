@@ -25,31 +25,51 @@ namespace {
 #else
 #define STAMP(i) do { } while (0)
 #endif
-#ifndef CTU_B64A
-#define CTU_B64A 0      // experiment: one-pass float2 transpose in the first pass (raises register pressure: spills)
+#ifndef CTU_ADDTID
+#define CTU_ADDTID 1    // transpose writes by ds_write_addtid_b32 (no address VGPR, 2 LDS cycles) into rows of 65 dwords
 #endif
-#ifndef CTU_LDSDMA
-#define CTU_LDSDMA 0    // experiment: second pass's PCM by LDS-DMA during the first pass (no gain, costs LDS cycles)
+#ifndef CTU_EXTEN_F64
+#define CTU_EXTEN_F64 1 // exten state (Navg, Yavg) and its update in double; the gain H from float seeds + one Newton step
 #endif
+
+// LDS store of one dword per lane at  M0 + OFF + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
+// what the transpose below writes (16 k1-rows of [frame slot][n2]).  M0 is set in the same statement; nothing else in
+// this kernel depends on M0.
+template <int OFF>
+__device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
+    // one wait state between the SALU write of M0 and an LDS add-TID instruction (ISA manual, required software nops)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" ::"v"(v), "s"(base), "n"(OFF) : "memory");
+}
+
 // MODE 0: 512-point real FFT, one frame per 16-lane group, NZ = rows of 32 samples, two passes of 4 frames.
 // MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
 //         (no twiddles in the untangle), NZ = rows of 16 samples, one pass of 8 frames.
 // VX:     also export what the VAD kernels need (kept out of the default instantiation: it costs registers).
 // NC:     coefficients accumulated per frame in phase 2 (16 or MAXC): a compile-time width keeps eight accumulators
-//         and a code path out of the common instantiation (9 -> 2 spilled VGPRs, +5 %).
+//         and a code path out of the common instantiation.
 // GEN:    GEN_PLAIN = the plain chain (DC removal on, power spectrum, no -fea_E, no exten, no intensity-loudness law,
-//         no diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills (+4 %).
+//         no diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills.
 //         GEN_INLD / GEN_EXTEN = the plain chain plus exactly that option (PLP; C4's noise reduction); GEN_FULL reads
 //         every flag at run time.
 // LPO:    LP order = number of cepstra when it is fixed at compile time (12: the PLP preset), 0 = run-time orders up to
-//         MAX_LP.  The unrolled Levinson / a->c tail then has no guards and no dead orders (22 spilled VGPRs -> 0).
-template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0>
+//         MAX_LP.  The unrolled Levinson / a->c tail then has no guards and no dead orders.
+// MD:     the DCT-II tail of phase 2 on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains): the band
+//         logarithms of a slot are the B operand as they stand (lane = frame + 8 h + 16 kk holds band group kk + 4 h),
+//         the folded DCT table is the A operand; FEAT_DCTC with NC = 16 only.
+//
+// Work distribution.  A tile is <= 64 consecutive frames of one utterance.  Stateless chains: the eight waves of a
+// workgroup share each tile (wave w takes frame slots 8w..8w+7).  Per-wave chains (p.per_wave; exten): every wave
+// walks its own list of tiles, eight frames at a time, and keeps the state that runs along an utterance in its
+// registers.  Either way a wave only touches its own eight P rows: no workgroup barrier after the table load.
+template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL;
+    static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
     const bool o_skip_phase2 = FULL ? p.skip_phase2 != 0 : false;
+    const bool per_wave = (GEN == GEN_EXTEN || FULL) ? p.per_wave != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
     float *ltab = lds + TILE * PSTRIDE;    // phase-2 tables (layout: KParams)
@@ -72,23 +92,32 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     __syncthreads();
     const float4 *lc = reinterpret_cast<const float4 *>(ltw + l16 * LTW_STRIDE);  // this lane's constant record
     const float4 *ltw4 = lc + (LC_TW >> 2);                                       // [0,8) stage twiddles, [8,12) untangle
+    float *const Pw = Pt + wave * 8 * PSTRIDE;  // this wave's eight P rows
+    // transpose scratch: rows 4-7 of the wave (4 x 260 = 16 x 65 dwords).  Pass A's spectra go to rows 0-3; pass B
+    // (and the single pass of the 256-point mode) overwrites the scratch with its own spectra after its transposes.
+    float *const scratch = Pw + 4 * PSTRIDE;
 
 #if CTU_STAMP
     unsigned long long st_acc[16] = {0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-    int tile = as_const(p.wg_first)[blockIdx.x];
+    int tile = as_const(p.wg_first)[per_wave ? blockIdx.x * NWAVE + wave : blockIdx.x];
     if (tile < 0) return;
     TileRec rec = load_rec(p.tiles, tile);
 
-    // samples x[i0-2 .. i0+1] of row j of frame slot f sit at pcm + sbase + f*wshift + 32 j + 2 l16 - 2
-    auto pcm_ptr = [&](const TileRec &r, int it) {
-        const int f = wave * 8 + it * 4 + fg;
-        const int fc = f < r.nvalid ? f : r.nvalid - 1;  // clamp: duplicates are computed but never stored
-        return p.pcm + r.sbase + (int64_t)fc * p.wshift + 2 * l16 - 2;
-    };
-    // exten NR state: thread = bin
-    float navg = 0.95f, yavg = 0.05f;
+    // exten NR state (src/nr/nr.cc:86-93): lane = bin (bin = lane + 64 j), carried along the wave's utterance
+    constexpr int NJ = MODE == 1 ? 3 : 5;  // ceil(K / 64): K = 129 / 257
+#if CTU_EXTEN_F64
+    typedef double xstate_t;
+#else
+    typedef float xstate_t;
+#endif
+    xstate_t navg[NJ], yavg[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        navg[j] = (xstate_t)0.95;
+        yavg[j] = (xstate_t)0.05;
+    }
 
     while (true) {
         const int nvalid = rec.nvalid;
@@ -96,27 +125,26 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         const int next = rec.next;
         TileRec nrec = rec;
         if (next >= 0) nrec = load_rec(p.tiles, next);
-        // this wave owns frame slots [8*wave, 8*wave+8) of the tile and the P rows of the same numbers
-        const int nv = min(max(nvalid - wave * 8, 0), 8);
+        const int nsub = per_wave ? (nvalid + 7) >> 3 : 1;
+        for (int sub = 0; sub < nsub; sub++) {
+        // this step's frame slots are [slot0, slot0 + 8) of the tile; their spectra live in the wave's P rows 0..7
+        const int slot0 = per_wave ? sub * 8 : wave * 8;
+        const int nv = min(max(nvalid - slot0, 0), 8);
 
         // ================= phase 1: frames -> power spectrum rows =================
-        // Pass A (frame slots 0-3 of the wave) loads its PCM from global memory and meanwhile has the PCM of
-        // pass B (slots 4-7) copied by LDS-DMA into the wave's rows 4-7, which nobody needs before pass B
-        // writes its spectra there.  The transpose scratch is rows 0-3 in pass A and rows 4-7 in pass B.
-        constexpr bool DMA = CTU_LDSDMA && (NZ <= 15) && MODE == 0;  // a frame's 32*NZ+8 samples must fit 64 lanes x 8 samples
         if (o_dbg != 2 && nv > 0) {
             const int npass = (MODE == 0 && nv > 4) ? 2 : 1;
-            // the pass body is instantiated twice (it = 0, 1) so that the choice of transpose is made at compile time
+            // the pass body is instantiated twice (it = 0, 1) so that row numbers are compile-time constants
             auto pass = [&](auto IT) {
                 constexpr int it = decltype(IT)::value;
-                const int f = wave * 8 + it * 4 + fg;  // frame slot in tile
-                const bool file_start = (l16 == 0) && (rec.t0 + (f < nvalid ? f : nvalid - 1) == 0);
-                float *scratch = Pt + (wave * 8 + (DMA ? 4 * it : 4)) * PSTRIDE;
+                const int f = slot0 + it * 4 + fg;  // frame slot in the tile (MODE 0)
+                const int fc = f < nvalid ? f : nvalid - 1;  // clamp: duplicates are computed but never stored
+                const bool file_start = (l16 == 0) && (rec.t0 + fc == 0);
                 STAMP(0);  // loop overhead / previous tail
                 float2 v[16];
                 if constexpr (MODE == 1) {
-                    // frames A = slot 2*fg, B = A+1 of this wave's 8; sample n = 16 j + l16 of each goes to re / im
-                    const int fa = wave * 8 + 2 * fg, fb_ = fa + 1;
+                    // frames A = slot 2*fg, B = A+1 of this step's 8; sample n = 16 j + l16 of each goes to re / im
+                    const int fa = slot0 + 2 * fg, fb_ = fa + 1;
                     const int ca = fa < nvalid ? fa : nvalid - 1, cb_ = fb_ < nvalid ? fb_ : nvalid - 1;
                     const int16_t *xa = p.pcm + rec.sbase + (int64_t)ca * p.wshift + l16;
                     const int16_t *xb = p.pcm + rec.sbase + (int64_t)cb_ * p.wshift + l16;
@@ -151,75 +179,54 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         }
                     }
                 } else {
-                float dc = 0.f;
-                pcm4 q[NZ];
-                if (!DMA || it == 0) {
-                    const int16_t *x = pcm_ptr(rec, it);
+                    float dc = 0.f;
+                    pcm4 q[NZ];
+                    // samples x[i0-2 .. i0+1] of row j of this lane's frame: i0 = 32 j + 2 l16
+                    const int16_t *x = p.pcm + rec.sbase + (int64_t)fc * p.wshift + 2 * l16 - 2;
 #pragma unroll
                     for (int j = 0; j < NZ; j++) q[j] = *reinterpret_cast<const pcm4 *>(x + 32 * j);
-                    if (DMA && npass == 2) {
-                        const int cl = lane < (32 * NZ + 8) / 8 ? lane : (32 * NZ + 8) / 8 - 1;  // 8-sample chunks of a frame
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int fb = wave * 8 + 4 + k;
-                            const int16_t *src = p.pcm + rec.sbase + (int64_t)(fb < nvalid ? fb : nvalid - 1) * p.wshift - 8 + 8 * cl;
-                            __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)(Pt + (wave * 8 + 4) * PSTRIDE + 256 * k), 16, 0, 0);
-                        }
-                    }
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA issued in pass A has landed
-                    const uint32_t *lp = reinterpret_cast<const uint32_t *>(Pt + (wave * 8 + 4) * PSTRIDE + 256 * fg) + 3 + l16;
 #pragma unroll
                     for (int j = 0; j < NZ; j++) {
-                        q[j].lo = lp[16 * j];
-                        q[j].hi = lp[16 * j + 1];
+                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
+                        const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
+                        float xm = (float)(int16_t)(q[j].lo >> 16);
+                        const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
+                        const float x1 = (float)(int16_t)(q[j].hi >> 16);
+                        if (j == 0) xm = file_start ? 0.f : xm;  // first sample of the file: history is 0
+                        const float y0 = w0 * (x0 - p.preem * xm);
+                        const float y1 = w1 * (x1 - p.preem * x0);  // w is 0 beyond the window
+                        v[j] = make_float2(y0, y1);
+                        dc += y0 + y1;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
 #pragma unroll
-                for (int j = 0; j < NZ; j++) {
-                    const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
-                    const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
-                    float xm = (float)(int16_t)(q[j].lo >> 16);
-                    const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
-                    const float x1 = (float)(int16_t)(q[j].hi >> 16);
-                    if (j == 0) xm = file_start ? 0.f : xm;  // first sample of the file: history is 0
-                    const float y0 = w0 * (x0 - p.preem * xm);
-                    const float y1 = w1 * (x1 - p.preem * x0);  // w is 0 beyond the window
-                    v[j] = make_float2(y0, y1);
-                    dc += y0 + y1;
-                }
+                    for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
+                    STAMP(1);  // PCM + window loads, convert, pre-emphasis, window
+                    if (o_remove_dc) {
+                        // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
+                        const float m = row16_allreduce_add(dc) * p.inv_window;
+                        if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
 #pragma unroll
-                for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
-                STAMP(1);  // PCM + window loads, convert, pre-emphasis, window
-                if (o_remove_dc) {
-                    // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
-                    const float m = row16_allreduce_add(dc) * p.inv_window;
-                    if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
+                            for (int j = 0; j < 16; j++) {
+                                const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
+                                v[j].x -= m * ((j & 1) ? mk.z : mk.x);
+                                v[j].y -= m * ((j & 1) ? mk.w : mk.y);
+                            }
+                        } else {  // exact instantiation: rows < NZ-1 are fully inside the window
+                            const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
 #pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
-                            v[j].x -= m * ((j & 1) ? mk.z : mk.x);
-                            v[j].y -= m * ((j & 1) ? mk.w : mk.y);
+                            for (int j = 0; j < NZ - 1; j++) {
+                                v[j].x -= m;
+                                v[j].y -= m;
+                            }
+                            v[NZ - 1].x -= m * (((NZ - 1) & 1) ? mk.z : mk.x);
+                            v[NZ - 1].y -= m * (((NZ - 1) & 1) ? mk.w : mk.y);
                         }
-                    } else {  // exact instantiation: rows < NZ-1 are fully inside the window
-                        const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
-#pragma unroll
-                        for (int j = 0; j < NZ - 1; j++) {
-                            v[j].x -= m;
-                            v[j].y -= m;
-                        }
-                        v[NZ - 1].x -= m * (((NZ - 1) & 1) ? mk.z : mk.x);
-                        v[NZ - 1].y -= m * (((NZ - 1) & 1) ? mk.w : mk.y);
                     }
-                }
-
                 }
                 STAMP(2);  // DC removal
                 // ---- stage 1: DFT16 over n1 (registers), lane = n2; then twiddle W256^(n2*k1)
                 dft16(v);
-                __builtin_amdgcn_sched_barrier(0);  // twiddles are L1 hits: fetch them just in time, not across the DFT
+                __builtin_amdgcn_sched_barrier(0);  // twiddles: fetch them just in time, not across the DFT
 #pragma unroll
                 for (int h = 0; h < 8; h++) {
                     const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
@@ -228,43 +235,61 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 STAMP(3);  // DFT16 #1 + twiddles
-                // ---- transpose [k1][n2] -> lane k1 holds all n2, through LDS.
-                //      element (k1,n2) of frame slot fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1): conflict-free
-                //      both ways.  Pass A has all 8 rows of the wave free: one pass of float2 (b64).  Pass B has only
-                //      rows 4-7 (rows 0-3 already hold pass A's spectra): re then im (b32).
+                // ---- transpose [k1][n2] -> lane k1 holds all n2, through the LDS scratch, re then im
+                __builtin_amdgcn_wave_barrier();
+#if CTU_ADDTID
+                // element (k1, n2) of frame group fg at dword  65 k1 + 16 fg + n2 = 65 k1 + lane: the stores are linear
+                // in the lane (ds_write_addtid_b32, no address register); lane k1 reads 65 k1 + 16 fg + n2, n2 = 0..15
+                // with immediate offsets: banks (k1 + 16 fg + n2) mod 32, distinct over each half wave
+                const uint32_t sbase = (uint32_t)(size_t)(lvoid_t *)scratch;
+                const float *rd = scratch + 65 * l16 + 16 * fg;
+#define TR_STORE(C)                                                                         \
+    lds_store_addtid<0 * 260>(v[0].C, sbase);   lds_store_addtid<1 * 260>(v[1].C, sbase);   \
+    lds_store_addtid<2 * 260>(v[2].C, sbase);   lds_store_addtid<3 * 260>(v[3].C, sbase);   \
+    lds_store_addtid<4 * 260>(v[4].C, sbase);   lds_store_addtid<5 * 260>(v[5].C, sbase);   \
+    lds_store_addtid<6 * 260>(v[6].C, sbase);   lds_store_addtid<7 * 260>(v[7].C, sbase);   \
+    lds_store_addtid<8 * 260>(v[8].C, sbase);   lds_store_addtid<9 * 260>(v[9].C, sbase);   \
+    lds_store_addtid<10 * 260>(v[10].C, sbase); lds_store_addtid<11 * 260>(v[11].C, sbase); \
+    lds_store_addtid<12 * 260>(v[12].C, sbase); lds_store_addtid<13 * 260>(v[13].C, sbase); \
+    lds_store_addtid<14 * 260>(v[14].C, sbase); lds_store_addtid<15 * 260>(v[15].C, sbase)
+                TR_STORE(x);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float re[16];
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) re[n2] = rd[n2];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                TR_STORE(y);
+#undef TR_STORE
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], rd[n2]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#else
+                // element (k1,n2) of frame group fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1): conflict-free both ways
                 const int sw = fg * 256;
                 const int par = fg & 1;
+#pragma unroll
+                for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].x;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (CTU_B64A && !DMA && it == 0) {
-                    float2 *sc2 = reinterpret_cast<float2 *>(Pt + wave * 8 * PSTRIDE);
+                float re[16];
 #pragma unroll
-                    for (int k1 = 0; k1 < 16; k1++) sc2[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                for (int n2 = 0; n2 < 16; n2++) re[n2] = scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int n2 = 0; n2 < 16; n2++) v[n2] = sc2[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                } else {
+                for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].y;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].x;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    float re[16];
-#pragma unroll
-                    for (int n2 = 0; n2 < 16; n2++) re[n2] = scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].y;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)]);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-
+                for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#endif
                 STAMP(4);  // LDS transpose
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
                 dft16(v);
@@ -273,7 +298,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 if constexpr (MODE == 1) {
                     // two real frames in one complex FFT: XA[k] = (Z[k] + conj Z[256-k])/2, XB[k] = (Z[k] - conj Z[256-k])/2i;
                     // bins 0..128 of both; the mirror bin comes from lane (16-k1)%16 as in MODE 0
-                    float *pa = Pt + (wave * 8 + 2 * fg) * PSTRIDE, *pb = pa + PSTRIDE;
+                    const int fa = slot0 + 2 * fg;
+                    float *pa = Pw + (2 * fg) * PSTRIDE, *pb = pa + PSTRIDE;
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) {
                         if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);
@@ -289,7 +315,6 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         pa[k] = 0.25f * (sr * sr + si * si);
                         pb[k] = 0.25f * (dr * dr + di * di);
                         if (VX && p.vad_export == 1) {  // XA = s/2, XB = (d)/(2i) = (di - i dr)/2
-                            const int fa = wave * 8 + 2 * fg;
                             if (fa < nvalid) p.xri[(rbase + fa) * 129 + k] = make_float2(0.5f * sr, 0.5f * si);
                             if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + k] = make_float2(0.5f * di, -0.5f * dr);
                         }
@@ -299,48 +324,47 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         pb[128] = v[8].y * v[8].y;
                         if (o_remove_dc) pa[0] = pb[0] = 1e-10f;
                         if (VX && p.vad_export == 1) {
-                            const int fa = wave * 8 + 2 * fg;
                             if (fa < nvalid) p.xri[(rbase + fa) * 129 + 128] = make_float2(v[8].x, 0.f);
                             if (fa + 1 < nvalid) p.xri[(rbase + fa + 1) * 129 + 128] = make_float2(v[8].y, 0.f);
                         }
                     }
                 } else {
-                // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
-                //      each together with its mirror bin 256-k held by lane (16-k1)%16 in register 15-k2
-                //      (register (16-k2)%16 for k1 = 0).
-                float *prow = Pt + f * PSTRIDE;
+                    // ---- untangle the packed real FFT and take |.|^2.  Lane k1 handles its bins k2=0..7,
+                    //      each together with its mirror bin 256-k held by lane (16-k1)%16 in register 15-k2
+                    //      (register (16-k2)%16 for k1 = 0).
+                    float *prow = Pw + (it * 4 + fg) * PSTRIDE;
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) {
-                    if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // two batches: bounds the registers in flight
-                    const float4 u4q = ltw4[8 + (k2 >> 1)];
-                    float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
-                    float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
-                    if (l16 == 0) {
-                        br = v[(16 - k2) & 15].x;
-                        bi = v[(16 - k2) & 15].y;
+                    for (int k2 = 0; k2 < 8; k2++) {
+                        if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // two batches: bounds the registers in flight
+                        const float4 u4q = ltw4[8 + (k2 >> 1)];
+                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
+                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        if (l16 == 0) {
+                            br = v[(16 - k2) & 15].x;
+                            bi = v[(16 - k2) & 15].y;
+                        }
+                        const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
+                        const float ar = v[k2].x, ai = v[k2].y;
+                        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                        const float tr = wr * di + wi * dr;
+                        const float ti = wi * di - wr * dr;
+                        const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
+                        const float pk = 0.25f * (ur * ur + ui * ui);
+                        const float pm = 0.25f * (vr * vr + vi * vi);
+                        const int k = l16 + 16 * k2;
+                        prow[k] = pk;
+                        prow[256 - k] = pm;
+                        if (VX && p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
+                            float2 *xo = p.xri + (rbase + f) * 257;
+                            xo[k] = make_float2(0.5f * ur, 0.5f * ui);
+                            xo[256 - k] = make_float2(0.5f * vr, -0.5f * vi);
+                        }
                     }
-                    const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
-                    const float ar = v[k2].x, ai = v[k2].y;
-                    const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
-                    const float tr = wr * di + wi * dr;
-                    const float ti = wi * di - wr * dr;
-                    const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
-                    const float pk = 0.25f * (ur * ur + ui * ui);
-                    const float pm = 0.25f * (vr * vr + vi * vi);
-                    const int k = l16 + 16 * k2;
-                    prow[k] = pk;
-                    prow[256 - k] = pm;
-                    if (VX && p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
-                        float2 *xo = p.xri + (rbase + f) * 257;
-                        xo[k] = make_float2(0.5f * ur, 0.5f * ui);
-                        xo[256 - k] = make_float2(0.5f * vr, -0.5f * vi);
+                    if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
+                        prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
+                        if (o_remove_dc) prow[0] = 1e-10f;
+                        if (VX && p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
                     }
-                }
-                if (l16 == 0) {  // bin 128 is its own mirror: X[128] = conj(Z[128]); bin 0 floor (src/io/in.cc:390)
-                    prow[128] = v[8].x * v[8].x + v[8].y * v[8].y;
-                    if (o_remove_dc) prow[0] = 1e-10f;
-                    if (VX && p.vad_export == 1 && f < nvalid) p.xri[(rbase + f) * 257 + 128] = make_float2(v[8].x, -v[8].y);
-                }
                 }
                 STAMP(6);  // untangle + P writes
             };
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         if (!o_fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
             for (int e = lane; e < nv * p.K; e += 64) {
                 const int f = e / p.K, k = e - f * p.K;
-                float *q_ = Pt + (wave * 8 + f) * PSTRIDE + k;
+                float *q_ = Pw + f * PSTRIDE + k;
                 *q_ = sqrtf(*q_);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -361,77 +385,120 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         }
 
         // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
-        // The only cross-wave step: one lane per bin walks the tile's frames in order (workgroup barriers).
-        if (o_nr_exten) {
-            __syncthreads();
-            if (rec.t0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
-                navg = 0.95f;
-                yavg = 0.05f;
-            }
-            if (tid < p.K) {
-                const float pp = p.nr_p, qq = 1.0f - p.nr_p;
-                for (int f = 0; f < nvalid; f++) {
-                    const float X = Pt[f * PSTRIDE + tid];
-                    // H = Navg / (Navg^a + Yavg^a)^(1/a); the output X - H X is formed as X (1 - H) with 1 - H written
-                    // without cancellation (fp32 here, double in the reference; double was measured: no accuracy gain,
-                    // -15 % on the main path through register allocation)
-                    // (v_rcp_f32 / v_rsq_f32, ~1 ulp, instead of IEEE division and square root: this loop is a serial chain)
-                    float H, omH;
-                    if (p.nr_a == 1.0f) {
-                        const float ir = __builtin_amdgcn_rcpf(navg + yavg);
-                        H = navg * ir;
-                        omH = yavg * ir;
-                    } else if (p.nr_a == 2.0f) {
-                        const float r2 = navg * navg + yavg * yavg;
-                        const float ir = __builtin_amdgcn_rsqf(r2);
-                        const float r = r2 * ir;
-                        H = navg * ir;
-                        omH = (yavg * yavg) * __builtin_amdgcn_rcpf(r * (r + navg));
-                    } else {
-                        H = navg / powf(powf(navg, p.nr_a) + powf(yavg, p.nr_a), 1.0f / p.nr_a);
-                        omH = 1.0f - H;
-                    }
-                    const float N = H * X;
-                    navg = pp * navg + qq * N;
-                    yavg = fabsf(X - navg);
-                    Pt[f * PSTRIDE + tid] = X * omH;
+        // Sequential in t, independent across bins: lane = bin (bin = lane + 64 j), the step's frames in order, the
+        // state (Navg, Yavg) in this wave's registers along its utterance (per-wave chains only).
+        if (o_nr_exten && nv > 0) {
+            if (rec.t0 == 0 && slot0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    navg[j] = (xstate_t)0.95;
+                    yavg[j] = (xstate_t)0.05;
                 }
             }
-            __syncthreads();
+            const xstate_t pp = (xstate_t)p.nr_p_d, qq = (xstate_t)1.0 - pp;
+            for (int f = 0; f < nv; f++) {
+                float *row = Pw + f * PSTRIDE + lane;
+                float X[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) X[j] = (lane + 64 * j < p.K) ? row[64 * j] : 1.f;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    // H = Navg / (Navg^a + Yavg^a)^(1/a); the output X - H X is formed as X (1 - H) with 1 - H written
+                    // without cancellation.  Double state: the reciprocal root / reciprocal start from the float
+                    // instructions and take one Newton step in double.
+#if CTU_EXTEN_F64
+                    const double na = navg[j], ya = yavg[j], Xd = (double)X[j];
+                    double H, omH;
+                    if (p.nr_a == 1.0f) {
+                        const double s_ = na + ya;
+                        double ir = (double)__builtin_amdgcn_rcpf((float)s_);
+                        ir = ir * (2.0 - s_ * ir);
+                        ir = ir * (2.0 - s_ * ir);
+                        H = na * ir;
+                        omH = ya * ir;
+                    } else if (p.nr_a == 2.0f) {
+                        const double r2 = na * na + ya * ya;
+                        double ir = (double)__builtin_amdgcn_rsqf((float)r2);
+                        ir = ir * (1.5 - 0.5 * r2 * ir * ir);
+                        ir = ir * (1.5 - 0.5 * r2 * ir * ir);
+                        const double r = r2 * ir, dn = r * (r + na);
+                        double id = (double)__builtin_amdgcn_rcpf((float)dn);
+                        id = id * (2.0 - dn * id);
+                        id = id * (2.0 - dn * id);
+                        H = na * ir;
+                        omH = (ya * ya) * id;
+                    } else {
+                        H = na / pow(pow(na, (double)p.nr_a) + pow(ya, (double)p.nr_a), 1.0 / (double)p.nr_a);
+                        omH = 1.0 - H;
+                    }
+                    const double N = H * Xd;
+                    navg[j] = pp * na + qq * N;
+                    yavg[j] = fabs(Xd - navg[j]);
+                    X[j] = (float)(Xd * omH);
+#else
+                    float H, omH;
+                    if (p.nr_a == 1.0f) {
+                        const float ir = __builtin_amdgcn_rcpf(navg[j] + yavg[j]);
+                        H = navg[j] * ir;
+                        omH = yavg[j] * ir;
+                    } else if (p.nr_a == 2.0f) {
+                        const float r2 = navg[j] * navg[j] + yavg[j] * yavg[j];
+                        const float ir = __builtin_amdgcn_rsqf(r2);
+                        const float r = r2 * ir;
+                        H = navg[j] * ir;
+                        omH = (yavg[j] * yavg[j]) * __builtin_amdgcn_rcpf(r * (r + navg[j]));
+                    } else {
+                        H = navg[j] / powf(powf(navg[j], p.nr_a) + powf(yavg[j], p.nr_a), 1.0f / p.nr_a);
+                        omH = 1.0f - H;
+                    }
+                    const float N = H * X[j];
+                    navg[j] = pp * navg[j] + qq * N;
+                    yavg[j] = fabsf(X[j] - navg[j]);
+                    X[j] = X[j] * omH;
+#endif
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    if (lane + 64 * j < p.K) row[64 * j] = X[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (VX && p.vad_export && nv > 0) {  // the VAD looks at in->_Xsabs after NR (src/io/batch.cc:230-240, src/vad/vad.cc:96-107,227-230)
             if (p.vad_export == 1) {
                 for (int e = lane; e < nv * p.K; e += 64) {
                     const int f = e / p.K, k = e - f * p.K;
-                    p.pnr[(rbase + wave * 8 + f) * p.K + k] = Pt[(wave * 8 + f) * PSTRIDE + k];
+                    p.pnr[(rbase + slot0 + f) * p.K + k] = Pw[f * PSTRIDE + k];
                 }
             } else {
                 const int f8e = lane >> 3, ge = lane & 7;
                 float es = 0.f;
                 for (int k = ge; k < p.K; k += 8) {
-                    const float x = Pt[(wave * 8 + f8e) * PSTRIDE + k];
+                    const float x = Pw[f8e * PSTRIDE + k];
                     es += x * x;
                 }
                 es = lanes8_allreduce_add(es);
-                if (ge == 0 && f8e < nv) p.pnr[rbase + wave * 8 + f8e] = es;
+                if (ge == 0 && f8e < nv) p.pnr[rbase + slot0 + f8e] = es;
             }
         }
         STAMP(7);  // hand-over to phase 2 (incl. NR)
 
         // ================= phase 2 (wave-local): lane = (frame, band group) =================
-        // The wave's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
+        // The step's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
         // 8 bands of a slot have similar widths; every group walks the same number of 4-bin chunks per slot.
         if (o_dbg != 1 && !o_skip_phase2 && nv > 0) {
-            const int f8 = lane >> 3, g = lane & 7;
-            const int fslot = wave * 8 + f8;
+            // lane -> (frame f8, group g).  MD: lane = f8 + 8 h + 16 kk with g = kk + 4 h, the B-operand layout of the MFMA
+            const int f8 = MD ? (lane & 7) : (lane >> 3), g = MD ? (((lane >> 3) & 1) * 4 + (lane >> 4)) : (lane & 7);
+            const int fslot = slot0 + f8;
             const bool fvalid = f8 < nv;
-            const float *prow2 = Pt + fslot * PSTRIDE;
+            const float *prow2 = Pw + f8 * PSTRIDE;
             float c[NC];
 #pragma unroll
             for (int i = 0; i < NC; i++) c[i] = 0.f;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             double esum = 0.0;  // -fea_E sums squares of values that may already be powers: beyond the float range on silent frames
             if (o_e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
-                const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : wave * 8) * p.wshift;
+                const int16_t *xr = p.pcm + rec.sbase + (int64_t)(f8 < nv ? fslot : slot0) * p.wshift;
                 for (int i = 1 + g; i < p.window; i += 8) {
                     const float x = (float)xr[i];
                     esum += (double)x * x;
@@ -450,10 +517,10 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 const int bidx = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2 + 1]);
                 const float4 *pq = reinterpret_cast<const float4 *>(prow2 + kstart);  // kstart is a multiple of 4
                 const float4 *wq = reinterpret_cast<const float4 *>(ltab) + cb * 8 + g;
-                float acc = 0.f, acc1 = 0.f;
+                float acc = 0.f, accb = 0.f;
                 const int nch = ce - cb;
                 int ch = 0;
-                for (; ch + 4 <= nch; ch += 4) {  // 4 chunks per group: 12 LDS reads in flight, then 16 FMAs
+                for (; ch + 4 <= nch; ch += 4) {  // 4 chunks per group: 8 LDS reads in flight, then 16 FMAs
                     float4 w4[4], p4[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) w4[u] = wq[(ch + u) * 8];
@@ -462,13 +529,13 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 #pragma unroll
                     for (int u = 0; u < 4; u += 2) {
                         acc += w4[u].x * p4[u].x;
-                        acc1 += w4[u + 1].x * p4[u + 1].x;
+                        accb += w4[u + 1].x * p4[u + 1].x;
                         acc += w4[u].y * p4[u].y;
-                        acc1 += w4[u + 1].y * p4[u + 1].y;
+                        accb += w4[u + 1].y * p4[u + 1].y;
                         acc += w4[u].z * p4[u].z;
-                        acc1 += w4[u + 1].z * p4[u + 1].z;
+                        accb += w4[u + 1].z * p4[u + 1].z;
                         acc += w4[u].w * p4[u].w;
-                        acc1 += w4[u + 1].w * p4[u + 1].w;
+                        accb += w4[u + 1].w * p4[u + 1].w;
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // DS reads
                     __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU
@@ -477,11 +544,11 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const float4 w4 = wq[ch * 8];
                     const float4 p4 = pq[ch];
                     acc += w4.x * p4.x;
-                    acc1 += w4.y * p4.y;
+                    accb += w4.y * p4.y;
                     acc += w4.z * p4.z;
-                    acc1 += w4.w * p4.w;
+                    accb += w4.w * p4.w;
                 }
-                acc += acc1;
+                acc += accb;
                 float y = acc;
                 if (o_fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
                 if (o_e_mode == 3 && bidx >= 0)  // band energy of the FB output, i.e. after its ^0.33 (src/fea/fea_impl.cc:44-50,68-74)
@@ -495,8 +562,16 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 } else {
                     if (FEAT == FEAT_LP && !o_fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
-                    const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
-                    cell_accumulate<NC>(c, cf, y);
+                    if constexpr (MD) {
+                        // D[m][n] += sum_kk A[m][kk] B[kk][n]: B = this slot's band logarithms as they stand (n = lane & 15,
+                        // kk = lane >> 4); A = DCT rows of the bands in groups kk (columns n < 8) or kk + 4 (columns n >= 8)
+                        const float a0 = ltab[p.am_off + (2 * sl) * 64 + lane], a1 = ltab[p.am_off + (2 * sl + 1) * 64 + lane];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, y, acc1, 0, 0, 0);
+                    } else {
+                        const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
+                        cell_accumulate<NC>(c, cf, y);
+                    }
                 }
             }
             STAMP(8);  // filter bank + per-band accumulation
@@ -506,7 +581,19 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 else if (o_e_mode == 4) e = (float)log(lanes8_allreduce_add(esum));
                 if (o_e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
             }
-            if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
+            if constexpr (MD) {
+                // frame f8's coefficients: columns f8 of acc0 (groups 0-3) + f8 + 8 of acc1 (groups 4-7); lane f8 + 16 j
+                // then holds output slots 4j .. 4j+3 (norm, lifter and the writer's c1..cN,c0 order are in the table)
+                float o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) o4[r] = acc0[r] + dpp_mov<0x128>(acc1[r]);  // row_ror:8 brings column n + 8
+                float *orow = p.rows + (rbase + fslot) * p.D + 4 * (lane >> 4);
+                if (fvalid && (lane & 8) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (4 * (lane >> 4) + r < p.ncoef_out) orow[r] = o4[r];
+                }
+            } else if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
                 cells_reduce<NC>(c);
                 float *orow = p.rows + (rbase + fslot) * p.D;
                 if (FEAT == FEAT_DCTC) {
@@ -523,9 +610,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     }
                 } else {
                     // c[k] = R[k], the autocorrelation by cosine iDFT (src/fea/fea_impl.cc:181-198); every lane of the
-                    // frame runs Levinson-Durbin in double (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
+                    // frame runs Levinson-Durbin (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
                     // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
-                    // fp32: with the cube-root (or squared) band energies the autocorrelation matrix is well
+                    // fp32: with the cube-root band energies the autocorrelation matrix is well
                     // conditioned; measured deviation from a double recursion ~1e-6 (tests/test_gpu_parity.py::test_c3_plp)
                     constexpr int PM = LPO ? LPO : MAX_LP;
                     const int P_ = LPO ? LPO : p.lporder, ncep_ = LPO ? LPO : p.ncep;
@@ -583,9 +670,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             }
             STAMP(10);  // reduction, tail, row store
         }
-        if (o_nr_exten) __syncthreads();  // the bin-wise NR pass of the next tile reads every wave's rows
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        }  // steps of 8 frames
         if (next < 0) break;
         rec = nrec;
     }

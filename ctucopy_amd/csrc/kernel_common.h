@@ -14,7 +14,7 @@ constexpr int GEN_PLAIN = 0, GEN_INLD = 1, GEN_EXTEN = 2, GEN_FULL = 3;  // fron
 constexpr int MAXC = 24;       // most coefficients accumulated per frame in phase 2 (cepstra incl. c0, or LP lags)
 constexpr int PCM_ALIGN = 8;   // utterance starts are multiples of this many samples
 constexpr int PCM_HEAD = 8;    // samples of padding before the first utterance (x[-2..-1] of frame 0 is loaded)
-constexpr int PCM_TAIL = 64;   // padding after the last one (loads run to the end of the 32-sample row)
+constexpr int PCM_TAIL = 512;  // padding after the last one: the generic instantiation loads 16 rows of 32 samples whatever the window
 
 // Per-lane constant record, one per l16 = lane & 15, streamed from L1 every pass instead of pinning
 // 70+ VGPRs:  [0,32) Hamming pairs (w[32j+2l], w[32j+2l+1]) j=0..15 | [32,64) 1/0 "sample is inside the
@@ -54,6 +54,9 @@ struct KParams {
     float nr_p, nr_a;
     unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
     int skip_phase2;  // signal output (row N3): spectra are exported, nothing is projected
+    int per_wave;     // chains per wave (wg_first has grid * NWAVE entries) instead of per workgroup
+    int am_off;       // MD instantiations: A operands of the DCT MFMAs [2 * NS][64] in the LDS tables
+    double nr_p_d;    // exten smoothing constant in double
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
 
@@ -146,6 +149,7 @@ __device__ __forceinline__ double lanes8_allreduce_add(double x) {
     return x;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 

@@ -11,7 +11,6 @@ namespace {
 // read straight from an LDS tile of log-mel frames.  Rows of G sum to zero, so each column is offset by its centre
 // value first (keeps the fp32 accumulation small).
 // One workgroup = 64 output frames of one utterance (4 waves x 16 frames), all bands.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NRB, int NSM>  // row blocks of 16 DCT coefficients (ndct <= 16*NRB); NSM >= ceil(traplen/4) tap groups
 __global__ __launch_bounds__(256) void trapdct_mfma_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
