@@ -29,7 +29,7 @@ namespace {
 #define CTU_ADDTID 1    // transpose writes by ds_write_addtid_b32 (no address VGPR, 2 LDS cycles) into rows of 65 dwords
 #endif
 #ifndef CTU_EXTEN_F64
-#define CTU_EXTEN_F64 1 // exten state (Navg, Yavg) and its update in double; the gain H from float seeds + one Newton step
+#define CTU_EXTEN_F64 0 // 1: exten state (Navg, Yavg) and its update in double.  Measured (tools/probes/sweep_err.py, exten_err.py): no accuracy gain - the residual is fp32 FFT noise amplified where a bin is almost fully suppressed - and -30 % throughput
 #endif
 
 // LDS store of one dword per lane at  M0 + OFF + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is

@@ -31,6 +31,22 @@ def split_list(n_items, world, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def lpt_shard(frames, world):
+    """Longest-processing-time partition of a list over `world` ranks: utterances sorted by frame count,
+    each handed to the rank with the least frames so far.  Returns one index array per rank (ascending list order inside
+    a rank, so outputs are written in list order); the rank loads differ by at most one utterance's frames."""
+    import heapq
+    frames = np.asarray(frames, dtype=np.int64)
+    order = np.argsort(-frames, kind="stable")
+    heap = [(0, r) for r in range(world)]
+    parts = [[] for _ in range(world)]
+    for i in order:
+        load, r = heapq.heappop(heap)
+        parts[r].append(int(i))
+        heapq.heappush(heap, (load + int(frames[i]), r))
+    return [np.array(sorted(p), dtype=np.int64) for p in parts]
+
+
 def reduce_timing(dt_seconds, frames, device=None):
     """(max over ranks of dt, sum over ranks of frames); identity when torch.distributed is not initialised."""
     import torch

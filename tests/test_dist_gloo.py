@@ -51,6 +51,19 @@ def test_split_list_covers_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_lpt_shard_balances_and_covers_the_list():
+    rng = np.random.default_rng(3)
+    frames = rng.integers(300, 1500, size=5000)
+    for world in (1, 2, 3, 8):
+        parts = shard.lpt_shard(frames, world)
+        allidx = np.concatenate(parts)
+        assert len(parts) == world and np.array_equal(np.sort(allidx), np.arange(frames.size))
+        assert all(np.all(np.diff(p) > 0) for p in parts)                  # list order inside a rank
+        loads = np.array([frames[p].sum() for p in parts])
+        assert loads.max() - loads.min() <= frames.max()                   # within one utterance
+    assert [p.tolist() for p in shard.lpt_shard([5, 1, 4], 2)] == [[0], [1, 2]]
+
+
 def test_lengths_are_deterministic_and_in_range():
     a, b = shard.utterance_lengths(1000, 5), shard.utterance_lengths(1000, 5)
     assert np.array_equal(a, b) and a.min() >= 48000 and a.max() <= 240000

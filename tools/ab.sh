@@ -1,11 +1,9 @@
 #!/bin/bash
-# usage: tools/ab.sh libA.so libB.so ...   -- interleaved A/B timing of engine builds in one GPU session
-for round in 1 2 3; do
-for lib in "$@"; do
-  CTU_ENGINE_LIB=$PWD/ctucopy_amd/$lib timeout -k 10 300 python bench.py --steps 10 --warmup 2 --utts 2000 --no-cpu 2>/dev/null > /tmp/ab.json
-  python - "$lib" <<'PY'
-import json,sys
-d=json.loads(open("/tmp/ab.json").read().strip().split("\n")[-1])
-print(sys.argv[1], "frames/s %.4g" % d["value"], "kernel_ms %.4f" % d["roofline"]["kernel_ms"], "frac %.4f" % d["roofline"]["frac"])
-PY
-done; done
+# usage: tools/ab.sh <cfg> <rounds> <lib1> <lib2> ...   -- interleaved A/B of engine builds on one device ("-" = the in-tree library)
+CFG=$1; ROUNDS=$2; shift 2
+for r in $(seq $ROUNDS); do
+  for L in "$@"; do
+    if [ "$L" = "-" ]; then unset CTU_ENGINE_LIB; else export CTU_ENGINE_LIB=$L; fi
+    echo -n "$L  "; python tools/bench_cfg.py --cfg $CFG --steps 10 | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('ms %.4f kernel %.4f' % (d['ms_per_step'], d['front_kernel_ms']))"
+  done
+done

@@ -4,8 +4,7 @@ import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bench import synth_arena
-from ctucopy_amd import Engine, shard
+from ctucopy_amd import Engine, shard, synth
 from tests.util import C2, C3, C4, C4_NOVAD, C5
 
 CFGS = {"C2": C2, "C3": C3, "C4": C4, "C4_novad": C4_NOVAD, "C5": C5, "C2_d_a": C2 + ["-fea_delta", "d_a"],
@@ -22,10 +21,11 @@ a = ap.parse_args()
 cfg = CFGS[a.cfg]
 eng = Engine(cfg)
 fs = eng.dims.fs
-lens = shard.utterance_lengths(a.utts, 7, lo=3 * fs, hi=15 * fs)
-plan = eng.plan(lens)
+set_id = synth.SET_NOISY if fs == 8000 else synth.SET_SPEECH   # S-NOISY for the 8 kHz configurations, S-MFCC otherwise
+idx = np.arange(a.utts)
+plan = eng.plan(synth.lengths(set_id, idx))
 dev = torch.device("cuda", 0)
-pcm = synth_arena(plan.total_samples, 1, dev)
+pcm = torch.from_numpy(synth.fill_arena(set_id, idx, plan.sample_off, plan.total_samples)).to(dev)
 if eng.dims.signal_out:
     out = torch.zeros(plan.total_samples, dtype=torch.int16, device=dev)
     for _ in range(2):
