@@ -27,6 +27,26 @@ def Engine():
     return E
 
 
+def _assert_rows(g, ref, cfg):
+    """The parity bound by conditioning class.
+
+    The stated 1e-4 (element-wise, |a-b| <= 1e-4 max(|b|, 1)) holds wherever the fp32 FFT's noise floor is below it:
+    pre-emphasis, DC removal, power spectra, no NR.  Without pre-emphasis / DC removal the low bins dominate the frame and
+    the floor rises; magnitude spectra halve the logarithms' margin; exten amplifies the floor where a bin is almost fully
+    suppressed (X (1-H) inherits err(X) Navg / Yavg - measured identical with the recurrence in double,
+    tools/probes/sweep_err.py).  Those configurations are held to 6e-4 element-wise AND to 1e-4 of the row's largest value."""
+    opt = {k: v for k, v in zip(cfg[:-1], cfg[1:]) if k.startswith("-")}
+    well = (float(opt.get("-preem", 0)) > 0 and opt.get("-remove_dc", "on") == "on" and opt.get("-fb_power", "on") == "on"
+            and opt.get("-nr_mode", "none") == "none")
+    err = rel_err(g, ref)
+    if well:
+        assert err <= TOL, (err, " ".join(cfg))
+    else:
+        rown = float((np.abs(g - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1.0)).max()) if ref.size else 0.0
+        assert err <= 6e-4 and rown <= 1e-4, (err, rown, " ".join(cfg))
+    return err
+
+
 def _check(Engine, cfg, utts, tol=TOL):
     eng = Engine(cfg)
     got = eng.extract(utts)
@@ -122,7 +142,7 @@ def test_c4_features_8khz(Engine):
     assert [g.shape[0] for g in got] == frames
 
 
-def _vad_agreement(Engine, cfg, utts, min_agree):
+def _vad_agreement(Engine, cfg, utts, min_agree, rows_by_row_norm=False):
     eng = Engine(cfg)
     rows, vads = eng.extract(utts, want_vad=True)
     orc = Oracle(cfg)
@@ -133,21 +153,26 @@ def _vad_agreement(Engine, cfg, utts, min_agree):
         agree += int((v == ref_vad).sum())
         total += v.size
         if "drop" not in cfg:
-            # Appendix-B C4 has no pre-emphasis; on the bundled 16 kHz recordings read at 8 kHz the spectrum tilts by
-            # ~80 dB and fp32 FFT noise reaches |d| ~ 1e-4 on rows whose values reach 85: 2e-4 element-wise (unit
-            # floor), 1e-5 relative to the row's largest value
-            assert r.shape == ref_rows.shape and rel_err(r, ref_rows) <= 2e-4
-            assert (np.abs(r - ref_rows).max(axis=1) <= 1e-5 * np.maximum(np.abs(ref_rows).max(axis=1), 1.0)).all()
+            assert r.shape == ref_rows.shape
+            if rows_by_row_norm:
+                # recordings sampled at 16 kHz read as 8 kHz, no pre-emphasis: the spectrum tilts by ~80 dB and the fp32
+                # FFT noise floor sits 1e-4 below values of 85 - bounded against the row's largest value instead
+                assert (np.abs(r - ref_rows).max(axis=1) <= 1e-5 * np.maximum(np.abs(ref_rows).max(axis=1), 1.0)).all()
+            else:
+                assert rel_err(r, ref_rows) <= TOL
     assert agree / total >= min_agree, (agree, total)
     return rows, vads
 
 
 def test_c4_burg_cepstral_vad(Engine):
-    # configs[3]: exten + Burg-cepstral VAD + MFCC at 8 kHz.  Decisions are discontinuous: agreement, not tolerance.
+    # configs[3]: exten + Burg-cepstral VAD + MFCC at 8 kHz.  Decisions are discontinuous: they must be identical, frame
+    # for frame.  Values at 1e-4 on the noisy 8 kHz set (tests/test_fixtures.py holds all 16 committed utterances).
+    from ctucopy_amd import synth
     from tests.util import C4
-    rows, vads = _vad_agreement(Engine, C4, [sig("CS3"), sig("CS0"), synth_utt(91, 24000, fs=8000)], 0.995)
+    _vad_agreement(Engine, C4, [synth.utterance_c(synth.SET_NOISY, i, True) for i in (1, 7)] + [synth_utt(91, 24000, fs=8000)], 1.0)
+    rows, vads = _vad_agreement(Engine, C4, [sig("CS3"), sig("CS0")], 1.0, rows_by_row_norm=True)
     assert vads[0].size == 1186
-    assert abs(int((vads[0] == ord("1")).sum()) - 626) <= 6   # the compiled reference wrote 626 ones
+    assert int((vads[0] == ord("1")).sum()) == 626   # the compiled reference wrote 626 ones
 
 
 @pytest.mark.parametrize("extra,min_agree", [
@@ -209,9 +234,9 @@ def test_delta_windows_orders_energy(Engine, extra):
 
 def test_delta_on_plp_cepstra(Engine):
     _check(Engine, C3 + ["-fea_delta", "d_a"], [sig("CS0"), sig("CS3"), synth_utt(5, 30000)])
+    from ctucopy_amd import synth
     c4f = "-fs 8000 -preset plpc -fea_delta d_a".split()
-    x = sig("CS3")[::2].copy()
-    _check(Engine, c4f, [x, synth_utt(6, 9000)], tol=2e-4)
+    _check(Engine, c4f, [synth.utterance_c(synth.SET_NOISY, 4, True), synth_utt(6, 9000, fs=8000)])
 
 
 @pytest.mark.parametrize("tw", [3, 5, 9, 33])
@@ -259,9 +284,7 @@ def test_cms(Engine, extra):
 
 
 def test_cms_after_exten(Engine):
-    # the fp32 exten recurrence leaves ~1e-4 absolute on c0 (~1.7e-6 of its magnitude, inside the bound of
-    # test_exten_16k); once the mean is gone that same absolute error is measured against |ref| < 1, hence 2e-4 here
-    _check(Engine, C2 + ["-nr_mode", "exten", "-fea_Z_exp", "1000"], _post_utts(), tol=2e-4)
+    _check(Engine, C2 + ["-nr_mode", "exten", "-fea_Z_exp", "1000"], _post_utts())
 
 
 def test_cms_on_plp(Engine):
@@ -404,13 +427,7 @@ def test_random_configurations_match_the_oracle(Engine, seed, fs):
         for u, g in zip(utts, eng.extract(utts)):
             ref = orc.process(u)
             assert g.shape == ref.shape and np.isfinite(g).all(), cfg
-            # no pre-emphasis / no DC removal / magnitude spectra raise the fp32 noise floor (see the note in
-            # _vad_agreement): 3e-4 element-wise, or 2e-5 of the row's largest value where a row mixes 80 with 0.01
-            rown = float((np.abs(g - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1.0)).max())
-            # exten in float: where a bin is almost fully suppressed the output X (1 - H) inherits err(H) / (1 - H); a narrow
-            # band made of such bins moves its log by ~1e-3 in a handful of frames (the reference runs the recurrence in double)
-            tol = 1e-3 if "exten" in cfg else 3e-4
-            assert rel_err(g, ref) <= tol or rown <= 2e-5, (rel_err(g, ref), rown, " ".join(cfg))
+            _assert_rows(g, ref, cfg)
         ran += 1
     assert ran >= 20, (ran, refused)
 
@@ -472,10 +489,5 @@ def test_many_ragged_utterances_walk_the_tile_chains(Engine, extra):
     want_vad = "-vad_out_mode" in extra
     got = eng.extract(utts, want_vad=True)[0] if want_vad else eng.extract(utts)
     assert [g.shape[0] for g in got] == frames
-    worst = 0.0
     for i in rng.choice(len(utts), 40, replace=False):  # the oracle is the slow side: check a random 40
-        ref = orc.process(utts[i])
-        worst = max(worst, rel_err(got[i], ref))
-    # exten in float leaves ~1e-4 absolute on c0 (test_exten_16k); behind CMS that is measured against |ref| < 1
-    # (test_cms_after_exten), and over 40 x 165 frames the tail reaches 3e-4
-    assert worst <= (4e-4 if "-fea_Z_exp" in extra else 2e-4 if "exten" in extra else TOL), worst
+        _assert_rows(got[i], orc.process(utts[i]), cfg)
