@@ -32,8 +32,9 @@
 
 
 #include "kernel_common.h"
-#include "frontend_kernel.h"
 #include "vad_kernels.h"
+#include "vad_fused.h"
+#include "frontend_kernel.h"
 #include "trap_kernel.h"
 
 namespace {
@@ -90,6 +91,7 @@ struct ctu_engine {
     DevBuf<int> itab;
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
+    bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
     bool per_wave = false;  // chains per wave (state along an utterance lives in a wave's registers)
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -225,11 +227,21 @@ struct Phase2Tables {
 #ifndef CTU_MD
 #define CTU_MD 1
 #endif
-bool md_eligible(const ctu::Design &d) {
+#ifndef CTU_VF
+#define CTU_VF 1
+#endif
+// the plain cepstral chain: what the specialised instantiations (GEN_PLAIN / GEN_EXTEN with MD) cover
+bool plain_cepstral(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
-    return CTU_MD && d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !o.do_vad() &&
-           !d.signal_out;
+    return d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !d.signal_out;
 }
+// Burg-cepstral VAD criterion fused into the front end (vad_fused.h): 256-point mode, 200-sample window, 14 coefficients (the preset's detector)
+bool vf_eligible(const ctu::Design &d) {
+    const ctu::Opts &o = d.o;
+    return CTU_VF && CTU_MD && plain_cepstral(d) && o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" &&
+           d.wfft == 256 && o.vad_lpc_coefs == VF_NC && d.window == VF_WINDOW;
+}
+bool md_eligible(const ctu::Design &d) { return CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d)); }
 
 void build_phase2(const ctu::Design &d, Phase2Tables &t) {
     t.md = md_eligible(d);
@@ -468,6 +480,7 @@ void build_tables(ctu_engine *e) {
     e->cf_off = t.cf_off;
     e->am_off = t.am_off;
     e->md = t.md;
+    e->vf = vf_eligible(d);
     e->tab_floats = t.tab_floats;
     e->NS = t.NS;
     e->CW = t.CW;
@@ -524,7 +537,15 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const int feat = e->feat;
     const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
     const bool narrow = kp.CW == 16;
-    if (e->md) {
+    if (e->vf) {
+        if (!(kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.fb_inld && feat == FEAT_DCTC && narrow && MODE == 1 && e->md))
+            throw std::runtime_error("internal: VF engine without the VF instantiation");
+        if constexpr (MODE == 1) {
+            if (kp.nr_exten) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_EXTEN, 0, true, true>, grid, s, kp);
+            else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_PLAIN, 0, true, true>, grid, s, kp);
+        }
+    }
+    else if (e->md) {
         if (!(base && !kp.fb_inld && feat == FEAT_DCTC && narrow)) throw std::runtime_error("internal: MD tables without the MD instantiation");
         if (kp.nr_exten) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_EXTEN, 0, true>, grid, s, kp);
         else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true>, grid, s, kp);
@@ -655,7 +676,7 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             const ctu::Opts &o = e->design->o;
             const ctu::Design &d = *e->design;
             e->do_vad = o.do_vad();
-            e->per_wave = o.nr_mode == "exten";  // state along an utterance: a wave per chain
+            e->per_wave = o.nr_mode == "exten" || e->vf;  // state along an utterance (exten, the VAD's recurrences): a wave per chain
             VadParams &vp = e->vp;
             std::memset(&vp, 0, sizeof vp);
             vp.K = d.K; vp.wfft = d.wfft; vp.window = d.window;
@@ -750,7 +771,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             r.nvalid = (int)std::min<int64_t>(TILE, T - t0);
             r.t0 = (int)t0;
             r.next = -1;
-            r.pad = 0;
+            r.T = (int)T;
             tiles.push_back(r);
         }
         uinfo[i] = make_int4((int)(ro & 0xffffffff), (int)(ro >> 32), (int)T, 0);
@@ -810,9 +831,11 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
         if (e->do_vad) {
             pl->d_row_off.upload(pl->row_off);
             if (e->vp.cri == 1) {
-                pl->xri.alloc((size_t)ro * d.K);
-                pl->pnr.alloc((size_t)ro * d.K);
-                pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
+                if (!e->vf) {
+                    pl->xri.alloc((size_t)ro * d.K);
+                    pl->pnr.alloc((size_t)ro * d.K);
+                }
+                if (!e->vf) pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
         if (d.signal_out) {
@@ -872,7 +895,11 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.band_log = d.kind != ctu::FeaKind::Spec;
         kp.band_to_scratch = d.kind == ctu::FeaKind::TrapDct;
         kp.lp_is_lpa = d.kind == ctu::FeaKind::Lpa;
-        kp.vad_export = signal ? 1 : (!e->do_vad ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0)));
+        kp.vad_export = signal ? 1 : ((!e->do_vad || e->vf) ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0)));
+        kp.vad_ci = pl->vad_ci.p;
+        kp.vad_nc = e->vp.ncoef;
+        kp.vad_out = d_vad;
+        kp.vad = e->vp;
         kp.skip_phase2 = signal ? 1 : 0;
         kp.tiles = pl->tiles.p;
         kp.wg_first = pl->wg_first.p;
@@ -949,7 +976,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         }
 #endif
         if (e->do_vad) {
-            if (e->vp.cri == 1) {
+            if (e->vp.cri == 1 && !e->vf) {
                 const dim3 g((unsigned)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 4));
                 const size_t bshm = (512 + (size_t)4 * 2 * (d.wfft / 2 + 4)) * 2 * sizeof(vreal);
 #define BURG_LAUNCH(Q, NC) hipLaunchKernelGGL((vad_burg_kernel<Q, NC>), g, dim3(256), bshm, s, pl->xri.p, pl->pnr.p, pl->vad_ci.p, e->vp, pl->total_frames)
@@ -962,8 +989,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 }
 #undef BURG_LAUNCH
             }
-            hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
-                               pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
+            if (!e->vf)  // the fused path replays the decisions in the wave that walks the utterance
+                hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
+                                   pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
             HIP_TRY(hipGetLastError());
         }
         if (d.kind == ctu::FeaKind::TrapDct) {

@@ -25,21 +25,9 @@ namespace {
 #else
 #define STAMP(i) do { } while (0)
 #endif
-#ifndef CTU_ADDTID
-#define CTU_ADDTID 1    // transpose writes by ds_write_addtid_b32 (no address VGPR, 2 LDS cycles) into rows of 65 dwords
-#endif
 #ifndef CTU_EXTEN_F64
 #define CTU_EXTEN_F64 0 // 1: exten state (Navg, Yavg) and its update in double.  Measured (tools/probes/sweep_err.py, exten_err.py): no accuracy gain - the residual is fp32 FFT noise amplified where a bin is almost fully suppressed - and -30 % throughput
 #endif
-
-// LDS store of one dword per lane at  M0 + OFF + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
-// what the transpose below writes (16 k1-rows of [frame slot][n2]).  M0 is set in the same statement; nothing else in
-// this kernel depends on M0.
-template <int OFF>
-__device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
-    // one wait state between the SALU write of M0 and an LDS add-TID instruction (ISA manual, required software nops)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" ::"v"(v), "s"(base), "n"(OFF) : "memory");
-}
 
 // MODE 0: 512-point real FFT, one frame per 16-lane group, NZ = rows of 32 samples, two passes of 4 frames.
 // MODE 1: 256-point real FFT, TWO frames per 16-lane group packed as re/im of the same 256-point complex FFT
@@ -61,10 +49,13 @@ __device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
 // workgroup share each tile (wave w takes frame slots 8w..8w+7).  Per-wave chains (p.per_wave; exten): every wave
 // walks its own list of tiles, eight frames at a time, and keeps the state that runs along an utterance in its
 // registers.  Either way a wave only touches its own eight P rows: no workgroup barrier after the table load.
-template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false>
+// VF:     Burg-cepstral VAD criterion fused in (vad_fused.h; 256-point mode): the step's eight time-domain frames are
+//         rebuilt from the spectra after NR with the original phases and their cepstra written for the decision replay.
+template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL;
     static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
+    static_assert(!VF || (MODE == 1 && !VX), "VF: 256-point mode, no spectrum export");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
@@ -119,6 +110,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         yavg[j] = (xstate_t)0.05;
     }
 
+    VadRun vrun;  // VF: the VAD's recurrences along the wave's utterance
+    if constexpr (VF) vad_run_reset(vrun);
+
     while (true) {
         const int nvalid = rec.nvalid;
         const int64_t rbase = rec.rbase;
@@ -130,6 +124,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // this step's frame slots are [slot0, slot0 + 8) of the tile; their spectra live in the wave's P rows 0..7
         const int slot0 = per_wave ? sub * 8 : wave * 8;
         const int nv = min(max(nvalid - slot0, 0), 8);
+        float2 vz[16];  // VF: the forward transform's output Z[l16 + 16 r], kept for the inverse
 
         // ================= phase 1: frames -> power spectrum rows =================
         if (o_dbg != 2 && nv > 0) {
@@ -237,63 +232,15 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 STAMP(3);  // DFT16 #1 + twiddles
                 // ---- transpose [k1][n2] -> lane k1 holds all n2, through the LDS scratch, re then im
                 __builtin_amdgcn_wave_barrier();
-#if CTU_ADDTID
-                // element (k1, n2) of frame group fg at dword  65 k1 + 16 fg + n2 = 65 k1 + lane: the stores are linear
-                // in the lane (ds_write_addtid_b32, no address register); lane k1 reads 65 k1 + 16 fg + n2, n2 = 0..15
-                // with immediate offsets: banks (k1 + 16 fg + n2) mod 32, distinct over each half wave
-                const uint32_t sbase = (uint32_t)(size_t)(lvoid_t *)scratch;
-                const float *rd = scratch + 65 * l16 + 16 * fg;
-#define TR_STORE(C)                                                                         \
-    lds_store_addtid<0 * 260>(v[0].C, sbase);   lds_store_addtid<1 * 260>(v[1].C, sbase);   \
-    lds_store_addtid<2 * 260>(v[2].C, sbase);   lds_store_addtid<3 * 260>(v[3].C, sbase);   \
-    lds_store_addtid<4 * 260>(v[4].C, sbase);   lds_store_addtid<5 * 260>(v[5].C, sbase);   \
-    lds_store_addtid<6 * 260>(v[6].C, sbase);   lds_store_addtid<7 * 260>(v[7].C, sbase);   \
-    lds_store_addtid<8 * 260>(v[8].C, sbase);   lds_store_addtid<9 * 260>(v[9].C, sbase);   \
-    lds_store_addtid<10 * 260>(v[10].C, sbase); lds_store_addtid<11 * 260>(v[11].C, sbase); \
-    lds_store_addtid<12 * 260>(v[12].C, sbase); lds_store_addtid<13 * 260>(v[13].C, sbase); \
-    lds_store_addtid<14 * 260>(v[14].C, sbase); lds_store_addtid<15 * 260>(v[15].C, sbase)
-                TR_STORE(x);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float re[16];
-#pragma unroll
-                for (int n2 = 0; n2 < 16; n2++) re[n2] = rd[n2];
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                TR_STORE(y);
-#undef TR_STORE
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], rd[n2]);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#else
-                // element (k1,n2) of frame group fg at  fg*256 + ((k1^(fg&1))<<4) + (n2^k1): conflict-free both ways
-                const int sw = fg * 256;
-                const int par = fg & 1;
-#pragma unroll
-                for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].x;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float re[16];
-#pragma unroll
-                for (int n2 = 0; n2 < 16; n2++) re[n2] = scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)];
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int k1 = 0; k1 < 16; k1++) scratch[sw + ((k1 ^ par) << 4) + (l16 ^ k1)] = v[k1].y;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], scratch[sw + ((l16 ^ par) << 4) + (n2 ^ l16)]);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#endif
+                wave_transpose16(v, (uint32_t)(size_t)(lvoid_t *)scratch, scratch + 65 * l16 + 16 * fg);
                 STAMP(4);  // LDS transpose
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
                 dft16(v);
                 STAMP(5);  // DFT16 #2
+                if constexpr (VF) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) vz[r] = v[r];
+                }
 
                 if constexpr (MODE == 1) {
                     // two real frames in one complex FFT: XA[k] = (Z[k] + conj Z[256-k])/2, XB[k] = (Z[k] - conj Z[256-k])/2i;
@@ -669,6 +616,50 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             STAMP(10);  // reduction, tail, row store
+        }
+        // ================= Burg-cepstral VAD criterion of the step's frames (vad_fused.h) =================
+        if constexpr (VF) {
+            if (nv > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float2 vn[16];
+                vf_scale_spectra(vz, vn, Pw + (2 * fg) * PSTRIDE, Pw + (2 * fg + 1) * PSTRIDE, l16, partner);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // every lane has its gains before the scratch (P rows 4-7) is reused
+                vf_inverse_fft(vn, ltw4, (uint32_t)(size_t)(lvoid_t *)scratch, scratch + 65 * l16 + 16 * fg);
+                // time-domain frames into the wave's LDS rows (the spectra are spent): frame slot s at s * VF_FSTRIDE
+                float *ta = Pw + (2 * fg) * VF_FSTRIDE + l16, *tb = ta + VF_FSTRIDE;
+#pragma unroll
+                for (int m = 0; m < VF_SPL; m++) {
+                    ta[16 * m] = vn[m].x;
+                    tb[16 * m] = vn[m].y;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float mine_ab[2];
+                for (int xb = 0; xb < 2; xb++) {  // frame A, then frame B of this 16-lane group
+                    const float *tx = Pw + (2 * fg + xb) * VF_FSTRIDE + VF_SPL * l16;
+                    float x[VF_SPL], cc[VF_NC];
+#pragma unroll
+                    for (int j = 0; j < VF_SPL; j++) x[j] = (VF_SPL * l16 + j < p.window) ? tx[j] : 0.f;  // the first `window` samples (src/vad/vad.cc:233)
+                    vf_burg_cepstrum<VF_NC, VF_JW>(x, l16, VF_LW, VF_JW, p.inv_window, cc);
+                    float mine = cc[0];
+#pragma unroll
+                    for (int m = 1; m < VF_NC; m++) mine = l16 == m ? cc[m] : mine;
+                    mine_ab[xb] = mine;  // lane 16 fg + i: coefficient i of frame slot 2 fg + xb
+                }
+                // decision replay of the step's frames, in order (vad_kernels.h): lane i takes coefficient i of frame s
+                if (rec.t0 == 0 && slot0 == 0) vad_run_reset(vrun);
+                uint8_t *vout = p.vad_out + (rbase - rec.t0);
+                for (int s_ = 0; s_ < nv; s_++) {
+                    const int src = ((16 * (s_ >> 1) + (lane & 15)) << 2);
+                    const float ca = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mine_ab[0])));
+                    const float cb = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mine_ab[1])));
+                    const double cil = lane < VF_NC ? (double)((s_ & 1) ? cb : ca) : 0.0;
+                    vad_frame(vrun, p.vad, rec.t0 + slot0 + s_, 0.0, cil, lane, vout);
+                }
+                if (rec.t0 + slot0 + nv == rec.T) vad_flush(vrun, p.vad, rec.T, lane, vout);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();

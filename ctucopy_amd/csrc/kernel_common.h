@@ -29,6 +29,17 @@ constexpr int LTW_STRIDE = 116, LTW_FLOATS = 16 * LTW_STRIDE;
 // band_log, band_to_scratch); LP covers lpc and lpa (runtime flag lp_is_lpa).
 enum FeatMode { FEAT_BANDS = 0, FEAT_DCTC = 2, FEAT_LP = 3 };
 
+// VAD module parameters (src/vad/vad.cc, src/vad/vad.h; used by vad_kernels.h and by the fused path of the front end)
+struct VadParams {
+    int K, wfft, window, ncoef;  // ncoef = vad_lpc_coefs (cepdist lpc) or feature vector length (cepdist fea)
+    int cri;                     // 0 energy, 1 cepdist-lpc, 2 cepdist-fea
+    int thr;                     // 0 absolute, 1 perc, 2 adapt, 3 dyn
+    int energy_db, cep_init, filter_order;
+    double cep_p, abs_thr, perc_thr, adapt_q, adapt_za, dyn_perc, dyn_min, qmaxinc, qmaxdec, qmindec, qmininc;
+    int perc_init, adapt_init, dyn_init;
+    int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
+};
+
 struct KParams {
     const int16_t *pcm;
     float *rows;
@@ -57,8 +68,16 @@ struct KParams {
     int per_wave;     // chains per wave (wg_first has grid * NWAVE entries) instead of per workgroup
     int am_off;       // MD instantiations: A operands of the DCT MFMAs [2 * NS][64] in the LDS tables
     double nr_p_d;    // exten smoothing constant in double
+    double *vad_ci;   // VF instantiations: [total_frames][vad_nc] Burg cepstra for the decision replay
+    int vad_nc;       // cepstral coefficients of the Burg criterion (vad_lpc_coefs)
+    uint8_t *vad_out; // VF instantiations: the VAD bytes ('0' / '1' per frame), written by the wave that walks the utterance
+    VadParams vad;    // VF instantiations: the decision replay's parameters
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -98,6 +117,49 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k = 0; k < 16; k++) t[k] = v[4 * (k & 3) + (k >> 2)];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = t[k];
+}
+
+// LDS store of one dword per lane at  M0 + OFF + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
+// what the transpose below writes (16 k1-rows of [frame slot][n2]).  M0 is set in the same statement; nothing else in
+// this kernel depends on M0.
+template <int OFF>
+__device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
+    // one wait state between the SALU write of M0 and an LDS add-TID instruction (ISA manual, required software nops)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" ::"v"(v), "s"(base), "n"(OFF) : "memory");
+}
+
+// Transpose of 16 x 16 complex values between "lane" and "register" inside each 16-lane group of a wave, through an LDS
+// scratch of 16 x 65 dwords (re, then im): element (k1, n2) of group fg sits at dword 65 k1 + 16 fg + n2 = 65 k1 + lane.
+// The stores are linear in the lane (ds_write_addtid_b32, no address register, 2 LDS cycles); lane k1 reads 65 k1 + 16 fg +
+// n2, n2 = 0..15, with immediate offsets: banks (k1 + 16 fg + n2) mod 32, distinct over each half wave.
+//   sbase = LDS byte address of the scratch (wave-uniform), rd = scratch + 65 * (lane & 15) + 16 * (lane >> 4).
+__device__ __forceinline__ void wave_transpose16(float2 (&v)[16], uint32_t sbase, const float *rd) {
+    __builtin_amdgcn_wave_barrier();
+#define TR_STORE(C)                                                                         \
+    lds_store_addtid<0 * 260>(v[0].C, sbase);   lds_store_addtid<1 * 260>(v[1].C, sbase);   \
+    lds_store_addtid<2 * 260>(v[2].C, sbase);   lds_store_addtid<3 * 260>(v[3].C, sbase);   \
+    lds_store_addtid<4 * 260>(v[4].C, sbase);   lds_store_addtid<5 * 260>(v[5].C, sbase);   \
+    lds_store_addtid<6 * 260>(v[6].C, sbase);   lds_store_addtid<7 * 260>(v[7].C, sbase);   \
+    lds_store_addtid<8 * 260>(v[8].C, sbase);   lds_store_addtid<9 * 260>(v[9].C, sbase);   \
+    lds_store_addtid<10 * 260>(v[10].C, sbase); lds_store_addtid<11 * 260>(v[11].C, sbase); \
+    lds_store_addtid<12 * 260>(v[12].C, sbase); lds_store_addtid<13 * 260>(v[13].C, sbase); \
+    lds_store_addtid<14 * 260>(v[14].C, sbase); lds_store_addtid<15 * 260>(v[15].C, sbase)
+    TR_STORE(x);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float re[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) re[n2] = rd[n2];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    TR_STORE(y);
+#undef TR_STORE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(re[n2], rd[n2]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Wave-uniform tables are read through constant-address-space pointers so that they become scalar
@@ -149,9 +211,6 @@ __device__ __forceinline__ double lanes8_allreduce_add(double x) {
     return x;
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator
-typedef __attribute__((address_space(1))) const void gvoid_t;
-typedef __attribute__((address_space(3))) void lvoid_t;
 
 struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-byte aligned
     uint32_t lo, hi;
@@ -179,10 +238,10 @@ __device__ __forceinline__ void cells_reduce(float (&c)[NCW]) {
 
 // Tile record (32 bytes, read with one scalar load): where the tile's first frame starts in the PCM
 // arena, where its first output row goes, how many of its 64 frame slots are real, the frame index of
-// slot 0 inside its utterance, and the next tile this workgroup walks (-1 = done).
+// slot 0 inside its utterance, the next tile this workgroup / wave walks (-1 = done), the utterance's frame count.
 struct TileRec {
     int64_t sbase, rbase;
-    int nvalid, t0, next, pad;
+    int nvalid, t0, next, T;  // T = frames of the tile's utterance
 };
 
 __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
@@ -193,7 +252,7 @@ __device__ __forceinline__ TileRec load_rec(const TileRec *tiles, int tile) {
     r.nvalid = w[4];
     r.t0 = w[5];
     r.next = w[6];
-    r.pad = 0;
+    r.T = w[7];
     return r;
 }
 

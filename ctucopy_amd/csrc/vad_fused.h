@@ -1,0 +1,176 @@
+// Burg-cepstral VAD criterion fused into the front end (256-point mode): the wave that computed a step's eight spectra
+// also rebuilds the eight time-domain frames the detector looks at and runs the Burg lattices, so neither the complex
+// spectra nor the time-domain frames go through HBM.  Included by frontend_kernel.h.
+//
+// Reference chain (src/vad/vad.cc:220-236): fft_in = Xsabs[k] cos / sin (Xsph[k]) with Xsabs the vector AFTER noise
+// reduction (a power spectrum when fb_power is on) and Xsph the phase of the ORIGINAL spectrum (src/io/in.cc:396-401);
+// unnormalised FFTW_HC2R; the first `window` samples go to Burg (src/vdet/Burg.h:49-95) and on to cepstra (:141-152).
+#pragma once
+
+namespace {
+
+// In-register 16-point inverse DFT (e^{+i...}): IDFT(x) = swap(DFT(swap(x))) with swap = exchange of re and im.
+__device__ __forceinline__ void idft16(float2 (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = make_float2(v[i].y, v[i].x);
+    dft16(v);
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = make_float2(v[i].y, v[i].x);
+}
+
+constexpr int VF_NC = 14;         // cepstral coefficients of the fused path (-vad_lpc_coefs default: Burg order 13)
+constexpr int VF_WINDOW = 200;    // the window the fused path is built for (8 kHz, 25 ms); other windows take the separate kernels
+constexpr int VF_SPL = 13;        // samples per lane of a frame: 16 lanes x 13 = 208 >= window
+constexpr int VF_LW = (VF_WINDOW - 1) / VF_SPL, VF_JW = (VF_WINDOW - 1) % VF_SPL;  // lane / register of the window's last sample
+constexpr int VF_FSTRIDE = 216;   // floats per time-domain frame in the LDS staging area: 2 x 216 = 16 (mod 32), so the two
+                                  // frame groups of a half wave read different banks; 8 x 216 <= the wave's 8 x 260
+
+// Stage A.  vz[r] = Z[l16 + 16 r] of the forward transform of (frame A + i frame B).  Every bin is scaled to the
+// magnitude the noise reduction left (P rows of the two frames) while it keeps its direction:
+//   XA'[k] = gA XA[k], XB'[k] = gB XB[k], g = Xsabs_after_NR / |X|  (bins 1..127; DC and Nyquist are real, see below)
+//   Z'[k] = XA'[k] + i XB'[k] = hA (sr, si) + hB (dr, di),  h = g / 2,  (sr, si, dr, di) the untangle sums of Z[k], Z[256-k]
+// and the same with the mirror's gains for k > 128 (Hermitian extension).
+__device__ __forceinline__ void vf_scale_spectra(const float2 (&vz)[16], float2 (&vn)[16], const float *rowA, const float *rowB,
+                                                 int l16, int partner) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - r].x)));
+        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - r].y)));
+        if (l16 == 0) {  // lane 0 holds its own mirrors: bin 16 r <-> bin 16 (16 - r)
+            br = vz[(16 - r) & 15].x;
+            bi = vz[(16 - r) & 15].y;
+        }
+        const int k = l16 + 16 * r, kt = r < 8 ? k : 256 - k;  // kt <= 128: where the gains live
+        const float pa = rowA[kt], pb = rowB[kt];             // Xsabs after NR
+        const float ar = vz[r].x, ai = vz[r].y;
+        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+        const float ma = sr * sr + si * si, mb = dr * dr + di * di;  // 4 |XA|^2, 4 |XB|^2
+        // 1 / (2 |X|) = rsqrt(4 |X|^2): v_rsq + one Newton step, as exact as its float input
+        float ia = __builtin_amdgcn_rsqf(ma), ib = __builtin_amdgcn_rsqf(mb);
+        ia = ia * (1.5f - 0.5f * ma * ia * ia);
+        ib = ib * (1.5f - 0.5f * mb * ib * ib);
+        const float ha = pa * ia, hb = pb * ib;
+        float xar = ha * sr, xai = ha * si;      // XA'[k]
+        float xbr = hb * di, xbi = -hb * dr;     // XB'[k] = gB (di, -dr) / 2
+        // |X| = 0: c_ph(0, 0) = -pi/2 (src/io/in.cc:191-193), so X' = -i Xsabs (+i on the mirrored side)
+        if (!(ma > 0.f)) { xar = 0.f; xai = r < 8 ? -pa : pa; }
+        if (!(mb > 0.f)) { xbr = 0.f; xbi = r < 8 ? -pb : pb; }
+        if (l16 == 0 && (r == 0 || r == 8)) {
+            // DC: phase 0; Nyquist: 0 or pi by the sign of the real part (src/io/in.cc:398-399); both purely real.
+            // Z[0] = XA[0] + i XB[0] and Z[128] likewise, with XA, XB real there.
+            xar = r == 0 ? pa : (ar >= 0.f ? pa : -pa);
+            xai = 0.f;
+            xbr = r == 0 ? pb : (ai >= 0.f ? pb : -pb);
+            xbi = 0.f;
+        }
+        vn[r] = make_float2(xar - xbi, xai + xbr);
+    }
+}
+
+// Stage B.  z[n] = sum_k Z'[k] e^{+2 pi i n k / 256} (unnormalised, FFTW_HC2R of the two Hermitian spectra at once): the
+// forward transform run backwards.  In: vn[k2] = Z'[k1 + 16 k2] in lane k1.  IDFT16 over k2 -> register m2; twiddle
+// W256^{-k1 m2} (the conjugate of the forward table, lane = k1); transpose; IDFT16 over k1 -> register m1:
+// out vn[m1] = z[l16 + 16 m1] = (frame A sample, frame B sample).
+__device__ __forceinline__ void vf_inverse_fft(float2 (&vn)[16], const float4 *ltw4, uint32_t sbase, const float *rd) {
+    idft16(vn);
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        const float4 tw = ltw4[h];  // W256^(l16 (2h+1)), W256^(l16 (2h+2))
+        vn[2 * h + 1] = cmul(vn[2 * h + 1], make_float2(tw.x, -tw.y));
+        if (2 * h + 2 < 16) vn[2 * h + 2] = cmul(vn[2 * h + 2], make_float2(tw.z, -tw.w));
+    }
+    wave_transpose16(vn, sbase, rd);
+    idft16(vn);
+}
+
+// Stages C + D.  One real frame per 16-lane group, 13 consecutive samples per lane (sample i = 13 l16 + j), zero beyond
+// `window`.  Burg lattice (src/vdet/Burg.h:49-95) with the order loop unrolled: the prediction coefficients are plain
+// registers, the same in every lane of the group; the two sums of an order are 16-lane DPP all-reduces.  Then the a -> c
+// recursion (Burg.h:141-152).  cc[0..NC-1] are the cepstra (cc[0] = ln alpha).
+//
+// Range handling without per-sample masks (every lane runs the same instructions):
+//   * the sums of order ik run over i >= ik (Burg.h:70-74).  Samples below 13 >= ik live in lane 0 only; ef[i < ik] and
+//     eb[i < ik - 1] are dead by then, so lane 0 zeroes ef[ik-1] and eb[ik-2] at the start of the order and they drop out;
+//   * eb[window-1] is written by every order but only ever read for the sample after the window: it is kept at zero
+//     (lane `lw`, register `jw`), which also keeps ef / eb at zero beyond the window;
+//   * eb[i-1] of a lane's first sample is the previous lane's last register (row_ror:1); lane 0 receives lane 15's,
+//     which lies beyond the window: zero.
+// JW >= 0: the register of eb[window-1] is known at compile time (window 200: lane 15, register 4); JW < 0: run-time jw.
+// NC = number of cepstral coefficients (orders 1..NC-1), a compile-time constant: straight-line code, no joins.
+template <int NC, int JW>
+__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l16, int lw, int jw, float inv_w, float (&cc)[NC]) {
+    float ef[VF_SPL], eb[VF_SPL];
+    float part = 0.f, part1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VF_SPL; j++) {
+        ef[j] = eb[j] = x[j];
+        if (j & 1) part1 += x[j] * x[j];
+        else part += x[j] * x[j];
+    }
+    float alpha = row16_allreduce_add(part + part1) * inv_w;  // Energy.h:38-44 / Burg.h:62
+    const bool lane0 = l16 == 0, lanew = l16 == lw;
+    auto clear_last = [&] {
+        if constexpr (JW >= 0) eb[JW] = lanew ? 0.f : eb[JW];
+        else {
+#pragma unroll
+            for (int j = 0; j < VF_SPL; j++)
+                if (j == jw) eb[j] = lanew ? 0.f : eb[j];
+        }
+    };
+    clear_last();
+    float a[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) a[i] = i == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int ik = 1; ik < NC; ik++) {
+        {
+            if (ik - 1 < VF_SPL) ef[ik - 1] = lane0 ? 0.f : ef[ik - 1];
+            if (ik >= 2 && ik - 2 < VF_SPL) eb[ik - 2] = lane0 ? 0.f : eb[ik - 2];
+            const float eb_prev = dpp_mov<0x121>(eb[VF_SPL - 1]);  // row_ror:1
+            float n0 = 0.f, n1 = 0.f, d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < VF_SPL; j++) {
+                const float bm = j == 0 ? eb_prev : eb[j - 1];
+                if (j & 1) {
+                    n1 += ef[j] * bm;
+                    d1 += ef[j] * ef[j];
+                    d1 += bm * bm;
+                } else {
+                    n0 += ef[j] * bm;
+                    d0 += ef[j] * ef[j];
+                    d0 += bm * bm;
+                }
+            }
+            const float num = row16_allreduce_add(n0 + n1);
+            const float den = row16_allreduce_add(d0 + d1);
+            const float rc = -(2.0f * num) / den;
+            alpha *= 1.0f - rc * rc;
+            float carry = eb_prev;
+#pragma unroll
+            for (int j = 0; j < VF_SPL; j++) {  // both updates from the old values (Burg.h:80-86)
+                const float bm = carry;
+                carry = eb[j];
+                const float nef = ef[j] + rc * bm, neb = bm + rc * ef[j];
+                ef[j] = nef;
+                eb[j] = neb;
+            }
+            clear_last();
+            float an[NC];
+#pragma unroll
+            for (int i = 1; i < ik; i++) an[i] = a[i] + rc * a[ik - i];
+#pragma unroll
+            for (int i = 1; i < ik; i++) a[i] = an[i];
+            a[ik] = rc;
+        }
+    }
+    cc[0] = __builtin_amdgcn_logf(alpha) * 0.69314718056f;
+#pragma unroll
+    for (int m = 1; m < NC; m++) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 1; k < m; k++) sum += (float)(m - k) * cc[m - k] * a[k];
+        cc[m] = -a[m] - sum * (1.0f / (float)m);
+    }
+}
+
+}  // namespace

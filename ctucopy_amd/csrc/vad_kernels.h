@@ -10,15 +10,6 @@ namespace {
 // (vad_decide_kernel) is one wave per utterance and replays the sequential, discontinuous part in double: cepstral
 // distance to the adaptive background, threshold recurrences, background update, majority ("median") filter.
 // ------------------------------------------------------------------------------------------------
-struct VadParams {
-    int K, wfft, window, ncoef;  // ncoef = vad_lpc_coefs (cepdist lpc) or feature vector length (cepdist fea)
-    int cri;                     // 0 energy, 1 cepdist-lpc, 2 cepdist-fea
-    int thr;                     // 0 absolute, 1 perc, 2 adapt, 3 dyn
-    int energy_db, cep_init, filter_order;
-    double cep_p, abs_thr, perc_thr, adapt_q, adapt_za, dyn_perc, dyn_min, qmaxinc, qmaxdec, qmindec, qmininc;
-    int perc_init, adapt_init, dyn_init;
-    int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
-};
 
 // vad_burg_kernel: one wave per frame (4 waves per workgroup, persistent): the frame's samples live in registers,
 // strided over the lanes (sample j = lane + 64 q); reductions are DPP row rotations + v_readlane (wave_sum_fast), no
@@ -204,9 +195,111 @@ __global__ __launch_bounds__(256) void vad_burg_kernel(const float2 *__restrict_
     }  // frames
 }
 
-// One wave per utterance (src/vad/vad.cc:220-294 distance + background, :329-625 thresholds, vad.h:126-175 filter).
-// The recurrences are sequential in t; the wave stages 64 frames of criterion inputs in LDS with coalesced loads,
-// then every lane replays them (same values in all lanes, lane 0 writes).
+// The sequential part of the VAD, one frame at a time, every lane of a wave in step (the state is wave-uniform except
+// c0r, the background cepstrum, which lane i keeps for coefficient i): cepstral distance to the adaptive background
+// (src/vad/vad.cc:220-294), the four threshold recurrences (:329-625), the majority filter (src/vad/vad.h:126-175).
+struct VadRun {
+    double crimin, crimax, crimean, crimean2, crivar, dmin, dmax;
+    double c0r;  // background cepstrum, coefficient `lane`
+    int adapt_vad;
+    unsigned long long hist;  // the last `order` (<= 31) raw decisions as bits, with a running count
+    int hidx, nout, nsum;
+};
+
+__device__ __forceinline__ void vad_run_reset(VadRun &r) {
+    r.crimin = r.crimax = r.crimean = r.crimean2 = r.crivar = r.dmin = r.dmax = 0.0;
+    r.c0r = 0.0;
+    r.adapt_vad = 0;
+    r.hist = 0;
+    r.hidx = r.nout = r.nsum = 0;
+}
+
+__device__ __forceinline__ void vad_push(VadRun &r, int v, int order) {
+    const int old = (int)((r.hist >> r.hidx) & 1ull);
+    r.hist = (r.hist & ~(1ull << r.hidx)) | ((unsigned long long)v << r.hidx);
+    r.nsum += v - old;
+    r.hidx = (r.hidx + 1 == order) ? 0 : r.hidx + 1;
+}
+
+// Frame t of an utterance.  en: the energy criterion's value (cri 0); cil: coefficient `lane` of the frame's cepstrum
+// (0 beyond nc).  out: the utterance's VAD bytes (lane 0 writes; decisions leave (order-1)/2 frames late).
+__device__ __forceinline__ void vad_frame(VadRun &r, const VadParams &vp, int t, double en, double cil, int lane, uint8_t *out) {
+    const int nc = vp.cri == 0 ? 1 : vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
+    double cri;
+    if (vp.cri == 0) {
+        if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
+        cri = en;
+    } else {
+        if (t == 0) {
+            r.c0r = cil;
+            cri = 0.0;
+        } else {
+            if (t == 1) r.c0r = (r.c0r + cil) / 2.0;
+            const double dl = (lane >= 1 && lane < nc) ? cil - r.c0r : 0.0;  // c0 itself is not part of the distance
+            cri = 4.3429 * sqrt(2 * wave_sum_fast(dl * dl));
+        }
+    }
+    int vad0;
+    if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
+    else if (vp.thr == 1) {
+        if (t == 0 || (double)t < (double)vp.perc_init) r.crimin = r.crimax = cri;
+        else {
+            r.crimin = cri < r.crimin ? cri : r.crimin;
+            r.crimax = cri > r.crimax ? cri : r.crimax;
+        }
+        vad0 = cri >= r.crimin + (vp.perc_thr / 100.0) * (r.crimax - r.crimin);
+    } else if (vp.thr == 2) {
+        if (t == 0) {
+            r.crimean = cri;
+            r.crimean2 = cri * cri;
+            r.crivar = 0.0;
+            r.adapt_vad = 0;
+        } else {
+            const double thr = r.crimean + vp.adapt_za * sqrt(r.crivar);
+            if (cri < thr || t <= vp.adapt_init) {
+                r.crimean = vp.adapt_q * r.crimean + (1.0 - vp.adapt_q) * cri;
+                r.crimean2 = vp.adapt_q * r.crimean2 + (1.0 - vp.adapt_q) * cri * cri;
+                r.crivar = r.crimean2 - r.crimean * r.crimean;
+                r.adapt_vad = 0;
+            } else r.adapt_vad = 1;
+        }
+        vad0 = r.adapt_vad;
+    } else {
+        const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
+        if (t < init) {
+            r.dmax = r.dmin = cri;
+            vad0 = 0;
+        } else if (t == init) {
+            r.dmax = (cri > r.dmax ? cri : r.dmax) + vp.dyn_min / 10.0;
+            r.dmin = (cri < r.dmin ? cri : r.dmin) - vp.dyn_min / 10.0;
+            vad0 = 0;
+        } else {
+            r.dmax = r.dmax < cri ? vp.qmaxinc * r.dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * r.dmax + (1.0 - vp.qmaxdec) * cri;
+            r.dmin = r.dmin > cri ? vp.qmindec * r.dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * r.dmin + (1.0 - vp.qmininc) * cri;
+            const double dyn = r.dmax - r.dmin;
+            vad0 = (cri > r.dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
+        }
+    }
+    if (vp.cri != 0 && !(vad0 && t > vp.cep_init))  // background update (src/vad/vad.cc:288-294)
+        r.c0r = vp.cep_p * r.c0r + (1.0 - vp.cep_p) * cil;
+    vad_push(r, vad0, order);
+    if (t >= h) {
+        if (lane == 0) out[r.nout] = ((double)r.nsum / (double)order >= 0.5) ? '1' : '0';
+        r.nout++;
+    }
+}
+
+// End of an utterance of T frames: zeros are pushed until every frame has its byte (src/vad/vad.h:156-175).
+__device__ __forceinline__ void vad_flush(VadRun &r, const VadParams &vp, int T, int lane, uint8_t *out) {
+    const int order = vp.filter_order, h = (order - 1) / 2;
+    for (int k = 0; k < h && r.nout < T; k++) {
+        vad_push(r, 0, order);
+        if (lane == 0) out[r.nout] = ((double)r.nsum / (double)order >= 0.5) ? '1' : '0';
+        r.nout++;
+    }
+}
+
+// One wave per utterance: stages 64 frames of criterion inputs in LDS with coalesced loads, then replays them.
 __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
                                                          const float *__restrict__ rows, const int64_t *__restrict__ row_off,
                                                          int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
@@ -215,19 +308,9 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
     if (u >= n_utt) return;
     const int64_t r0 = row_off[u];
     const int T = (int)(row_off[u + 1] - r0);
-    const int nc = vp.cri == 0 ? 1 : vp.ncoef, order = vp.filter_order, h = (order - 1) / 2;
-    // majority filter (src/vad/vad.h:126-175): the last `order` (<= 31) raw decisions as bits, with a running count
-    unsigned long long hist = 0;
-    int hidx = 0, nout = 0, nsum = 0;
-    auto push = [&](int v) {
-        const int old = (int)((hist >> hidx) & 1ull);
-        hist = (hist & ~(1ull << hidx)) | ((unsigned long long)v << hidx);
-        nsum += v - old;
-        hidx = (hidx + 1 == order) ? 0 : hidx + 1;
-    };
-    double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
-    int adapt_vad = 0;
-    double c0r = 0.0;  // background cepstrum, coefficient `lane` (src/vad/vad.cc:220-294)
+    const int nc = vp.cri == 0 ? 1 : vp.ncoef;
+    VadRun run;
+    vad_run_reset(run);
     for (int tb = 0; tb < T; tb += 64) {
         const int nt = min(64, T - tb);
         __syncthreads();
@@ -244,78 +327,12 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
         }
         __syncthreads();
         for (int tt = 0; tt < nt; tt++) {
-            const int t = tb + tt;
-            double cri, cil = 0.0;
-            if (vp.cri == 0) {
-                double en = stage[tt];
-                if (vp.energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
-                cri = en;
-            } else {
-                cil = lane < nc ? stage[tt * nc + lane] : 0.0;
-                if (t == 0) {
-                    c0r = cil;
-                    cri = 0.0;
-                } else {
-                    if (t == 1) c0r = (c0r + cil) / 2.0;
-                    const double dl = (lane >= 1 && lane < nc) ? cil - c0r : 0.0;  // c0 itself is not part of the distance
-                    cri = 4.3429 * sqrt(2 * wave_sum_fast(dl * dl));
-                }
-            }
-            int vad0;
-            if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
-            else if (vp.thr == 1) {
-                if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
-                else {
-                    crimin = cri < crimin ? cri : crimin;
-                    crimax = cri > crimax ? cri : crimax;
-                }
-                vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
-            } else if (vp.thr == 2) {
-                if (t == 0) {
-                    crimean = cri;
-                    crimean2 = cri * cri;
-                    crivar = 0.0;
-                    adapt_vad = 0;
-                } else {
-                    const double thr = crimean + vp.adapt_za * sqrt(crivar);
-                    if (cri < thr || t <= vp.adapt_init) {
-                        crimean = vp.adapt_q * crimean + (1.0 - vp.adapt_q) * cri;
-                        crimean2 = vp.adapt_q * crimean2 + (1.0 - vp.adapt_q) * cri * cri;
-                        crivar = crimean2 - crimean * crimean;
-                        adapt_vad = 0;
-                    } else adapt_vad = 1;
-                }
-                vad0 = adapt_vad;
-            } else {
-                const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
-                if (t < init) {
-                    dmax = dmin = cri;
-                    vad0 = 0;
-                } else if (t == init) {
-                    dmax = (cri > dmax ? cri : dmax) + vp.dyn_min / 10.0;
-                    dmin = (cri < dmin ? cri : dmin) - vp.dyn_min / 10.0;
-                    vad0 = 0;
-                } else {
-                    dmax = dmax < cri ? vp.qmaxinc * dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * dmax + (1.0 - vp.qmaxdec) * cri;
-                    dmin = dmin > cri ? vp.qmindec * dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * dmin + (1.0 - vp.qmininc) * cri;
-                    const double dyn = dmax - dmin;
-                    vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
-                }
-            }
-            if (vp.cri != 0 && !(vad0 && t > vp.cep_init))  // background update (src/vad/vad.cc:288-294)
-                c0r = vp.cep_p * c0r + (1.0 - vp.cep_p) * cil;
-            push(vad0);
-            if (t >= h) {
-                if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
-                nout++;
-            }
+            const double en = vp.cri == 0 ? stage[tt] : 0.0;
+            const double cil = (vp.cri != 0 && lane < nc) ? stage[tt * nc + lane] : 0.0;
+            vad_frame(run, vp, tb + tt, en, cil, lane, vad_out + r0);
         }
     }
-    for (int k = 0; k < h && nout < T; k++) {  // flush: zeros pushed (src/vad/vad.h:156-175)
-        push(0);
-        if (lane == 0) vad_out[r0 + nout] = ((double)nsum / (double)order >= 0.5) ? '1' : '0';
-        nout++;
-    }
+    vad_flush(run, vp, T, lane, vad_out + r0);
 }
 
 }  // namespace
