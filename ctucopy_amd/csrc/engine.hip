@@ -92,6 +92,8 @@ struct ctu_engine {
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
     bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
+    int ss = 0;             // hwss / fwss / 2fwss (1 / 2 / 3) on frontend_kernel<..., SS>
+    int han_off = 0;
     bool per_wave = false;  // chains per wave (state along an utterance lives in a wave's registers)
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -116,6 +118,8 @@ struct ctu_plan {
     int grid = 0;               // workgroups of the front-end launch (tile chains are built for it)
     DevBuf<TileRec> tiles;
     DevBuf<int> wg_first;
+    DevBuf<int> tile_utt;            // utterance of every tile (SS)
+    DevBuf<float> ss_seed, ss_last;  // SS: noise seeds per utterance [n_utt][K] and the vectors the utterances leave behind
     DevBuf<float2> xri;         // VAD scratch
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
@@ -135,6 +139,8 @@ struct ctu_plan {
 namespace {
 
 void set_error(ctu_engine *e, const std::string &m) { e->err = m; }
+
+bool ss_eligible(const ctu::Design &d);
 
 // reasons a valid ctucopy configuration is outside the accelerated path
 std::string unsupported_reason(const ctu::Design &d) {
@@ -157,7 +163,10 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.fea_kind == "td-iir-mfcc" || o.fea_kind == "none") return "fea_kind outside the spectral feature path";
     if (o.dither != 0.) return "-dither != 0 makes outputs depend on file order (src/io/in.cc:205,454)";
     if (o.remove_dc1) return "-remove_dc1 mutates the sample history across frames (src/io/in.cc:343-350)";
-    if (o.nr_mode != "none" && o.nr_mode != "exten") return "nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221)";
+    if (o.nr_mode != "none" && o.nr_mode != "exten") {
+        if (o.vadmode == "file") return "-vad file=...: one byte stream for all files, every byte but NUL counts as speech (src/nr/nr.cc:297-301)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (8 kHz, 25 ms window, -vad burg, 12 cepstral coefficients, plain chain)";
+    }
     if (o.nr_when_afterFB) return "-nr_when afterFB";
     if (o.rasta) return "-nr_rasta";
     if (d.post_order > 0) {
@@ -219,7 +228,7 @@ struct Phase2Tables {
     std::vector<float> ft;   // LDS image followed by the lifter
     std::vector<int> it;     // slot_chunk[NS+1] | row_slot[nfea]
     std::vector<int> cells, slot_chunk;
-    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, han_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;  // lane map of the MFMA tail: lane = frame + 8 h + 16 kk, group = kk + 4 h
 };
 
@@ -242,6 +251,16 @@ bool vf_eligible(const ctu::Design &d) {
            d.wfft == 256 && o.vad_lpc_coefs == VF_NC && d.window == VF_WINDOW;
 }
 bool md_eligible(const ctu::Design &d) { return CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d)); }
+// hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 256-point mode, 200-sample window, the
+// presets' 12 cepstral coefficients for the detector, the plain chain into cepstra or band energies
+int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode == "fwss" ? 2 : o.nr_mode == "2fwss" ? 3 : 0; }
+bool ss_eligible(const ctu::Design &d) {
+    const ctu::Opts &o = d.o;
+    const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
+    return CTU_MD && ss_mode_of(o) && o.vadmode == "burg" && !o.nr_when_afterFB && d.wfft == 256 && d.window == VF_WINDOW &&
+           o.fea_ncepcoefs == SS_NC && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !o.do_vad() && !d.signal_out &&
+           !o.rasta && d.post_order == 0 && !d.cms && !o.stat_cmvn && !o.apply_cmvn;
+}
 
 void build_phase2(const ctu::Design &d, Phase2Tables &t) {
     t.md = md_eligible(d);
@@ -395,6 +414,12 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
                     ft.push_back(v);
                 }
     }
+    if (ss_eligible(d)) {
+        // Hann window of the *ss modes' detector, han[i] = 0.5 (1 - cos(2 * 3.141592653 / window * i)) (src/vdet/CepstralDet.h:133-136)
+        t.han_off = (int)ft.size();
+        const double m = 2 * 3.141592653 / d.window;
+        for (int i = 0; i < 16 * VF_SPL; i++) ft.push_back(i < d.window ? (float)(0.5 * (1 - std::cos(m * i))) : 0.f);
+    }
     t.tab_floats = (int)ft.size();
     t.NS = NS;
     t.CW = CW;
@@ -481,6 +506,8 @@ void build_tables(ctu_engine *e) {
     e->am_off = t.am_off;
     e->md = t.md;
     e->vf = vf_eligible(d);
+    e->ss = ss_eligible(d) ? ss_mode_of(d.o) : 0;
+    e->han_off = t.han_off;
     e->tab_floats = t.tab_floats;
     e->NS = t.NS;
     e->CW = t.CW;
@@ -537,7 +564,14 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const int feat = e->feat;
     const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
     const bool narrow = kp.CW == 16;
-    if (e->vf) {
+    if (e->ss) {
+        if constexpr (MODE == 1) {
+            if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
+            else if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, 1, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
+            else throw std::runtime_error("internal: SS engine without an SS instantiation");
+        }
+    }
+    else if (e->vf) {
         if (!(kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.fb_inld && feat == FEAT_DCTC && narrow && MODE == 1 && e->md))
             throw std::runtime_error("internal: VF engine without the VF instantiation");
         if constexpr (MODE == 1) {
@@ -676,7 +710,7 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             const ctu::Opts &o = e->design->o;
             const ctu::Design &d = *e->design;
             e->do_vad = o.do_vad();
-            e->per_wave = o.nr_mode == "exten" || e->vf;  // state along an utterance (exten, the VAD's recurrences): a wave per chain
+            e->per_wave = o.nr_mode == "exten" || e->vf || e->ss;  // state along an utterance (exten, the VAD's recurrences): a wave per chain
             VadParams &vp = e->vp;
             std::memset(&vp, 0, sizeof vp);
             vp.K = d.K; vp.wfft = d.wfft; vp.window = d.window;
@@ -828,6 +862,14 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
         HIP_TRY(hipSetDevice(e->device));
         pl->tiles.upload(tiles);
         pl->wg_first.upload(wg_first);
+        if (e->ss) {
+            std::vector<int> tu(tiles.size());
+            for (int i = 0; i < n_utt; i++)
+                for (int t = uts[i]; t < uts[i + 1]; t++) tu[t] = i;
+            pl->tile_utt.upload(tu);
+            pl->ss_seed.alloc((size_t)std::max(n_utt, 1) * d.K);
+            pl->ss_last.alloc((size_t)std::max(n_utt, 1) * d.K);
+        }
         if (e->do_vad) {
             pl->d_row_off.upload(pl->row_off);
             if (e->vp.cri == 1) {
@@ -898,6 +940,14 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.vad_export = signal ? 1 : ((!e->do_vad || e->vf) ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0)));
         kp.vad_ci = pl->vad_ci.p;
         kp.vad_nc = e->vp.ncoef;
+        kp.ss_mode = e->ss;
+        kp.ss_init = d.o.nr_initsegs;
+        kp.han_off = e->han_off;
+        kp.nr_b = (float)d.o.nr_b;
+        kp.ss_q = d.o.nr_q;
+        kp.ss_seed = pl->ss_seed.p;
+        kp.ss_last = pl->ss_last.p;
+        kp.tile_utt = pl->tile_utt.p;
         kp.vad_out = d_vad;
         kp.vad = e->vp;
         kp.skip_phase2 = signal ? 1 : 0;
@@ -932,6 +982,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.lift_off = e->lift_off;
         kp.preem = d.o.preem;
         kp.inv_window = 1.0f / (float)d.window;
+        kp.inv_window_d = 1.0 / (double)d.window;
         kp.remove_dc = d.o.remove_dc;
         kp.fb_power = d.o.fb_power;
         kp.fb_inld = d.o.fb_inld;
@@ -952,9 +1003,35 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.stamps = e->stamps.p;
 #endif
         HIP_TRY(hipEventRecord(e->ev0, s));
-        switch (e->nz) {
-            case 13: e->mode ? launch_vx<13, 1>(e, dim3(grid), s, kp) : launch_vx<13, 0>(e, dim3(grid), s, kp); break;
-            default: e->mode ? launch_vx<16, 1>(e, dim3(grid), s, kp) : launch_vx<16, 0>(e, dim3(grid), s, kp); break;
+        auto launch = [&] {
+            switch (e->nz) {
+                case 13: e->mode ? launch_vx<13, 1>(e, dim3(grid), s, kp) : launch_vx<13, 0>(e, dim3(grid), s, kp); break;
+                default: e->mode ? launch_vx<16, 1>(e, dim3(grid), s, kp) : launch_vx<16, 0>(e, dim3(grid), s, kp); break;
+            }
+        };
+        if (!e->ss) launch();
+        else {
+            // hwss / fwss / 2fwss: a file's noise estimate starts from the vector the previous file of the list left
+            // behind (src/nr/nr.cc:212-221), which chains the whole list.  Everything but that seed is independent per
+            // file, so the list is run with the seeds known so far until they stop changing: pass j fixes the seeds of
+            // the first j files for good, and a seed's influence dies out as p^(noise updates), so real lists settle in
+            // two or three passes.  Synchronous: each pass reads the vectors back.
+            const size_t nk = (size_t)pl->n_utt * d.K;
+            std::vector<float> seed(nk, 0.f), last(nk, 0.f), next(nk, 0.f);
+            for (int iter = 0;; iter++) {
+                HIP_TRY(hipMemcpyAsync(pl->ss_seed.p, seed.data(), nk * sizeof(float), hipMemcpyHostToDevice, s));
+                launch();
+                HIP_TRY(hipMemcpyAsync(last.data(), pl->ss_last.p, nk * sizeof(float), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                int prev = -1;  // the last file before this one that had a frame: its vector is what new_file() finds
+                for (int i = 0; i < pl->n_utt; i++) {
+                    if (prev >= 0) std::memcpy(&next[(size_t)i * d.K], &last[(size_t)prev * d.K], d.K * sizeof(float));
+                    if (pl->frames[i] > 0) prev = i;
+                }
+                if (std::memcmp(next.data(), seed.data(), nk * sizeof(float)) == 0) break;
+                if (iter > pl->n_utt) throw std::runtime_error("internal: noise seeds of the *ss chain did not settle");
+                seed = next;
+            }
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

@@ -51,16 +51,20 @@ namespace {
 // registers.  Either way a wave only touches its own eight P rows: no workgroup barrier after the table load.
 // VF:     Burg-cepstral VAD criterion fused in (vad_fused.h; 256-point mode): the step's eight time-domain frames are
 //         rebuilt from the spectra after NR with the original phases and their cepstra written for the decision replay.
-template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false>
+// SS:     spectral subtraction with the Burg cepstral detector (hwss / fwss / 2fwss, src/nr/nr.cc:181-442; 256-point
+//         mode): the detector sees the frames rebuilt from the (expanded) spectra, so a step runs phase 1 twice - once to
+//         feed the detector, whose transposes and frames use up the P rows, once more for the subtraction itself.
+template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL;
     static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
     static_assert(!VF || (MODE == 1 && !VX), "VF: 256-point mode, no spectrum export");
+    static_assert(!SS || (MODE == 1 && !VX && !VF && GEN == GEN_PLAIN), "SS: 256-point mode, plain chain");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
     const bool o_skip_phase2 = FULL ? p.skip_phase2 != 0 : false;
-    const bool per_wave = (GEN == GEN_EXTEN || FULL) ? p.per_wave != 0 : false;
+    const bool per_wave = (GEN == GEN_EXTEN || FULL || VF || SS) ? p.per_wave != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
     float *ltab = lds + TILE * PSTRIDE;    // phase-2 tables (layout: KParams)
@@ -112,6 +116,11 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 
     VadRun vrun;  // VF: the VAD's recurrences along the wave's utterance
     if constexpr (VF) vad_run_reset(vrun);
+    CepDetRun sdet;            // SS: the cepstral detector's recurrences along the wave's utterance
+    float snavg[NJ], snrav[NJ];  // SS: noise estimate(s), lane = bin
+#pragma unroll
+    for (int j = 0; j < NJ; j++) snavg[j] = snrav[j] = 0.f;
+    if constexpr (SS) cepdet_reset(sdet);
 
     while (true) {
         const int nvalid = rec.nvalid;
@@ -127,6 +136,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         float2 vz[16];  // VF: the forward transform's output Z[l16 + 16 r], kept for the inverse
 
         // ================= phase 1: frames -> power spectrum rows =================
+        auto phase1 = [&] {
         if (o_dbg != 2 && nv > 0) {
             const int npass = (MODE == 0 && nv > 4) ? 2 : 1;
             // the pass body is instantiated twice (it = 0, 1) so that row numbers are compile-time constants
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
                 dft16(v);
                 STAMP(5);  // DFT16 #2
-                if constexpr (VF) {
+                if constexpr (VF || SS) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) vz[r] = v[r];
                 }
@@ -320,6 +330,120 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        };
+        phase1();
+        // The step's eight time-domain frames rebuilt from the P rows (magnitudes) and vz (directions), then the Burg
+        // cepstra of each (vad_fused.h).  Uses up the wave's P rows.  out[x]: lane 16 fg + i holds coefficient i of frame
+        // slot 2 fg + x.  HANN: the detector of the *ss modes windows the frame first (src/vdet/CepstralDet.h:131-147).
+        auto rebuild_cepstra = [&](auto NCO, auto HANN, auto (&out)[2]) {
+            constexpr int nco = decltype(NCO)::value;
+            typedef std::remove_reference_t<decltype(out[0])> real_t;  // float, or double for the *ss detector (vad_fused.h)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float2 vn[16];
+            vf_scale_spectra(vz, vn, Pw + (2 * fg) * PSTRIDE, Pw + (2 * fg + 1) * PSTRIDE, l16, partner);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // every lane has its gains before the scratch (P rows 4-7) is reused
+            vf_inverse_fft(vn, ltw4, (uint32_t)(size_t)(lvoid_t *)scratch, scratch + 65 * l16 + 16 * fg);
+            // time-domain frames into the wave's LDS rows (the spectra are spent): frame slot s at s * VF_FSTRIDE
+            float *ta = Pw + (2 * fg) * VF_FSTRIDE + l16, *tb = ta + VF_FSTRIDE;
+#pragma unroll
+            for (int m = 0; m < VF_SPL; m++) {
+                ta[16 * m] = vn[m].x;
+                tb[16 * m] = vn[m].y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int xb = 0; xb < 2; xb++) {  // frame A, then frame B of this 16-lane group
+                const float *tx = Pw + (2 * fg + xb) * VF_FSTRIDE + VF_SPL * l16;
+                float x[VF_SPL];
+                real_t cc[nco];
+#pragma unroll
+                for (int j = 0; j < VF_SPL; j++) x[j] = (VF_SPL * l16 + j < p.window) ? tx[j] : 0.f;  // the first `window` samples (src/vad/vad.cc:233)
+                if constexpr (decltype(HANN)::value) {
+                    const float *hw = ltab + p.han_off + VF_SPL * l16;
+#pragma unroll
+                    for (int j = 0; j < VF_SPL; j++) x[j] *= hw[j];
+                }
+                vf_burg_cepstrum<nco, VF_JW, real_t>(x, l16, VF_LW, VF_JW, (real_t)p.inv_window_d, cc);
+                real_t mine = cc[0];
+#pragma unroll
+                for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
+                out[xb] = mine;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        // ================= hwss / fwss / 2fwss (src/nr/nr.cc:181-442) =================
+        if constexpr (SS) {
+            if (nv > 0) {
+                const bool two = p.ss_mode == 3;
+                const int utt = as_const(p.tile_utt)[tile];
+                if (rec.t0 == 0 && slot0 == 0) {  // new_file (nr.cc:212-221, 402-409): seed from the previous file's last vector
+                    cepdet_reset(sdet);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        const float sd = (lane + 64 * j < p.K) ? p.ss_seed[(int64_t)utt * p.K + lane + 64 * j] : 0.f;
+                        snavg[j] = two ? sd : ss_pow(sd, p.nr_a);
+                        snrav[j] = 0.f;
+                    }
+                }
+                // (1) what the detector sees: X^a (X itself in 2fwss) with the original phase (nr.cc:278-295)
+                if (!two && p.nr_a != 1.0f) {
+                    for (int f = 0; f < nv; f++) {
+                        float *row = Pw + f * PSTRIDE + lane;
+#pragma unroll
+                        for (int j = 0; j < NJ; j++)
+                            if (lane + 64 * j < p.K) row[64 * j] = ss_pow(row[64 * j], p.nr_a);
+                    }
+                }
+                double mine_ab[2];
+                rebuild_cepstra(std::integral_constant<int, SS_NC>{}, std::true_type{}, mine_ab);
+                // (2) the detector's recurrences over the step's frames, in order (src/vdet/CepstralDet.h:140-194)
+                unsigned vbits = 0;
+                for (int s_ = 0; s_ < nv; s_++) {
+                    const int src = ((16 * (s_ >> 1) + (lane & 15)) << 2);
+                    const double sel = (s_ & 1) ? mine_ab[1] : mine_ab[0];
+                    const double got = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(sel)),
+                                                        __builtin_amdgcn_ds_bpermute(src, __double2loint(sel)));
+                    const double cil = lane < SS_NC ? got : 0.0;
+                    vbits |= (unsigned)cepdet_frame(sdet, cil, lane, SS_NC, p.ss_init, p.nr_p_d, p.ss_q) << s_;
+                }
+                // (3) the spectra again, then the subtraction proper, frames in order, lane = bin
+                phase1();
+                const float pp = p.nr_p, qq = 1.0f - p.nr_p;
+                for (int f = 0; f < nv; f++) {
+                    const int t = rec.t0 + slot0 + f;
+                    // hwss counts its initial segments down before the test, the others after it (nr.cc:225 vs :367, :440)
+                    const bool upd = !((vbits >> f) & 1u) || t < (p.ss_mode == 1 ? p.ss_init - 1 : p.ss_init);
+                    float *row = Pw + f * PSTRIDE + lane;
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        if (lane + 64 * j < p.K) {
+                            float X = row[64 * j];
+                            if (two) {
+                                if (upd) snavg[j] = pp * snavg[j] + qq * X;
+                                X = fabsf(X - snavg[j]);
+                                if (upd) snrav[j] = pp * snrav[j] + qq * X;
+                                X = fabsf(X - snrav[j]);
+                            } else {
+                                X = ss_pow(X, p.nr_a);
+                                if (upd) snavg[j] = pp * snavg[j] + qq * X;
+                                X -= p.nr_b * snavg[j];
+                                X = p.ss_mode == 1 ? fmaxf(X, 0.f) : fabsf(X);
+                                X = ss_root(X, p.nr_a);
+                            }
+                            row[64 * j] = X;
+                            if (t == rec.T - 1) p.ss_last[(int64_t)utt * p.K + lane + 64 * j] = X;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
 
         if (!o_fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
             for (int e = lane; e < nv * p.K; e += 64) {
@@ -620,34 +744,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // ================= Burg-cepstral VAD criterion of the step's frames (vad_fused.h) =================
         if constexpr (VF) {
             if (nv > 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float2 vn[16];
-                vf_scale_spectra(vz, vn, Pw + (2 * fg) * PSTRIDE, Pw + (2 * fg + 1) * PSTRIDE, l16, partner);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // every lane has its gains before the scratch (P rows 4-7) is reused
-                vf_inverse_fft(vn, ltw4, (uint32_t)(size_t)(lvoid_t *)scratch, scratch + 65 * l16 + 16 * fg);
-                // time-domain frames into the wave's LDS rows (the spectra are spent): frame slot s at s * VF_FSTRIDE
-                float *ta = Pw + (2 * fg) * VF_FSTRIDE + l16, *tb = ta + VF_FSTRIDE;
-#pragma unroll
-                for (int m = 0; m < VF_SPL; m++) {
-                    ta[16 * m] = vn[m].x;
-                    tb[16 * m] = vn[m].y;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
                 float mine_ab[2];
-                for (int xb = 0; xb < 2; xb++) {  // frame A, then frame B of this 16-lane group
-                    const float *tx = Pw + (2 * fg + xb) * VF_FSTRIDE + VF_SPL * l16;
-                    float x[VF_SPL], cc[VF_NC];
-#pragma unroll
-                    for (int j = 0; j < VF_SPL; j++) x[j] = (VF_SPL * l16 + j < p.window) ? tx[j] : 0.f;  // the first `window` samples (src/vad/vad.cc:233)
-                    vf_burg_cepstrum<VF_NC, VF_JW>(x, l16, VF_LW, VF_JW, p.inv_window, cc);
-                    float mine = cc[0];
-#pragma unroll
-                    for (int m = 1; m < VF_NC; m++) mine = l16 == m ? cc[m] : mine;
-                    mine_ab[xb] = mine;  // lane 16 fg + i: coefficient i of frame slot 2 fg + xb
-                }
+                rebuild_cepstra(std::integral_constant<int, VF_NC>{}, std::false_type{}, mine_ab);
                 // decision replay of the step's frames, in order (vad_kernels.h): lane i takes coefficient i of frame s
                 if (rec.t0 == 0 && slot0 == 0) vad_run_reset(vrun);
                 uint8_t *vout = p.vad_out + (rbase - rec.t0);

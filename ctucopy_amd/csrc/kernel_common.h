@@ -68,8 +68,18 @@ struct KParams {
     int per_wave;     // chains per wave (wg_first has grid * NWAVE entries) instead of per workgroup
     int am_off;       // MD instantiations: A operands of the DCT MFMAs [2 * NS][64] in the LDS tables
     double nr_p_d;    // exten smoothing constant in double
+    double inv_window_d;
     double *vad_ci;   // VF instantiations: [total_frames][vad_nc] Burg cepstra for the decision replay
     int vad_nc;       // cepstral coefficients of the Burg criterion (vad_lpc_coefs)
+    // SS instantiations (hwss / fwss / 2fwss): mode 1 / 2 / 3, oversubtraction b, initial noise-only frames, the detector's q,
+    // the noise seeds of the utterances (the previous file's last vector) and where each utterance leaves its own,
+    // the utterance of every tile, and the detector's Hann window [208] in the LDS tables
+    int ss_mode, ss_init, han_off;
+    float nr_b;
+    double ss_q;
+    const float *ss_seed;
+    float *ss_last;
+    const int *tile_utt;
     uint8_t *vad_out; // VF instantiations: the VAD bytes ('0' / '1' per frame), written by the wave that walks the utterance
     VadParams vad;    // VF instantiations: the decision replay's parameters
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production

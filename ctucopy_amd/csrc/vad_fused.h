@@ -19,6 +19,7 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 }
 
 constexpr int VF_NC = 14;         // cepstral coefficients of the fused path (-vad_lpc_coefs default: Burg order 13)
+constexpr int SS_NC = 12;         // the *ss modes' detector uses -fea_ncepcoefs coefficients (src/nr/nr.cc:266-268): 12 in the presets
 constexpr int VF_WINDOW = 200;    // the window the fused path is built for (8 kHz, 25 ms); other windows take the separate kernels
 constexpr int VF_SPL = 13;        // samples per lane of a frame: 16 lanes x 13 = 208 >= window
 constexpr int VF_LW = (VF_WINDOW - 1) / VF_SPL, VF_JW = (VF_WINDOW - 1) % VF_SPL;  // lane / register of the window's last sample
@@ -97,40 +98,50 @@ __device__ __forceinline__ void vf_inverse_fft(float2 (&vn)[16], const float4 *l
 //     which lies beyond the window: zero.
 // JW >= 0: the register of eb[window-1] is known at compile time (window 200: lane 15, register 4); JW < 0: run-time jw.
 // NC = number of cepstral coefficients (orders 1..NC-1), a compile-time constant: straight-line code, no joins.
-template <int NC, int JW>
-__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l16, int lw, int jw, float inv_w, float (&cc)[NC]) {
-    float ef[VF_SPL], eb[VF_SPL];
-    float part = 0.f, part1 = 0.f;
+// T = float (the VAD module's criterion: identical decisions to the double oracle on every test recording) or double
+// (the *ss modes' detector: it sees spectra raised to the power a, whose frames are nearly sinusoidal - reflection
+// coefficients within 1e-6 of +-1 - and a float lattice then loses the cepstra's digits that the threshold test needs).
+template <int NC, int JW, class T>
+__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
+    T ef[VF_SPL], eb[VF_SPL];
+    T part = 0, part1 = 0;
 #pragma unroll
     for (int j = 0; j < VF_SPL; j++) {
-        ef[j] = eb[j] = x[j];
-        if (j & 1) part1 += x[j] * x[j];
-        else part += x[j] * x[j];
+        ef[j] = eb[j] = (T)x[j];
+        if (j & 1) part1 += ef[j] * ef[j];
+        else part += ef[j] * ef[j];
     }
-    float alpha = row16_allreduce_add(part + part1) * inv_w;  // Energy.h:38-44 / Burg.h:62
+    auto row_sum = [](T v) {
+        v += dpp_mov<0x128>(v);  // row_ror:8
+        v += dpp_mov<0x124>(v);  // row_ror:4
+        v += dpp_mov<0x122>(v);  // row_ror:2
+        v += dpp_mov<0x121>(v);  // row_ror:1
+        return v;
+    };
+    T alpha = row_sum(part + part1) * inv_w;  // Energy.h:38-44 / Burg.h:62
     const bool lane0 = l16 == 0, lanew = l16 == lw;
     auto clear_last = [&] {
-        if constexpr (JW >= 0) eb[JW] = lanew ? 0.f : eb[JW];
+        if constexpr (JW >= 0) eb[JW] = lanew ? (T)0 : eb[JW];
         else {
 #pragma unroll
             for (int j = 0; j < VF_SPL; j++)
-                if (j == jw) eb[j] = lanew ? 0.f : eb[j];
+                if (j == jw) eb[j] = lanew ? (T)0 : eb[j];
         }
     };
     clear_last();
-    float a[NC];
+    T a[NC];
 #pragma unroll
-    for (int i = 0; i < NC; i++) a[i] = i == 0 ? 1.f : 0.f;
+    for (int i = 0; i < NC; i++) a[i] = i == 0 ? (T)1 : (T)0;
 #pragma unroll
     for (int ik = 1; ik < NC; ik++) {
         {
-            if (ik - 1 < VF_SPL) ef[ik - 1] = lane0 ? 0.f : ef[ik - 1];
-            if (ik >= 2 && ik - 2 < VF_SPL) eb[ik - 2] = lane0 ? 0.f : eb[ik - 2];
-            const float eb_prev = dpp_mov<0x121>(eb[VF_SPL - 1]);  // row_ror:1
-            float n0 = 0.f, n1 = 0.f, d0 = 0.f, d1 = 0.f;
+            if (ik - 1 < VF_SPL) ef[ik - 1] = lane0 ? (T)0 : ef[ik - 1];
+            if (ik >= 2 && ik - 2 < VF_SPL) eb[ik - 2] = lane0 ? (T)0 : eb[ik - 2];
+            const T eb_prev = dpp_mov<0x121>(eb[VF_SPL - 1]);  // row_ror:1
+            T n0 = 0, n1 = 0, d0 = 0, d1 = 0;
 #pragma unroll
             for (int j = 0; j < VF_SPL; j++) {
-                const float bm = j == 0 ? eb_prev : eb[j - 1];
+                const T bm = j == 0 ? eb_prev : eb[j - 1];
                 if (j & 1) {
                     n1 += ef[j] * bm;
                     d1 += ef[j] * ef[j];
@@ -141,21 +152,21 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l
                     d0 += bm * bm;
                 }
             }
-            const float num = row16_allreduce_add(n0 + n1);
-            const float den = row16_allreduce_add(d0 + d1);
-            const float rc = -(2.0f * num) / den;
-            alpha *= 1.0f - rc * rc;
-            float carry = eb_prev;
+            const T num = row_sum(n0 + n1);
+            const T den = row_sum(d0 + d1);
+            const T rc = -((T)2 * num) / den;
+            alpha *= (T)1 - rc * rc;
+            T carry = eb_prev;
 #pragma unroll
             for (int j = 0; j < VF_SPL; j++) {  // both updates from the old values (Burg.h:80-86)
-                const float bm = carry;
+                const T bm = carry;
                 carry = eb[j];
-                const float nef = ef[j] + rc * bm, neb = bm + rc * ef[j];
+                const T nef = ef[j] + rc * bm, neb = bm + rc * ef[j];
                 ef[j] = nef;
                 eb[j] = neb;
             }
             clear_last();
-            float an[NC];
+            T an[NC];
 #pragma unroll
             for (int i = 1; i < ik; i++) an[i] = a[i] + rc * a[ik - i];
 #pragma unroll
@@ -163,14 +174,57 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l
             a[ik] = rc;
         }
     }
-    cc[0] = __builtin_amdgcn_logf(alpha) * 0.69314718056f;
+    if constexpr (sizeof(T) == 8) cc[0] = log(alpha);
+    else cc[0] = __builtin_amdgcn_logf(alpha) * 0.69314718056f;
 #pragma unroll
     for (int m = 1; m < NC; m++) {
-        float sum = 0.f;
+        T sum = 0;
 #pragma unroll
-        for (int k = 1; k < m; k++) sum += (float)(m - k) * cc[m - k] * a[k];
-        cc[m] = -a[m] - sum * (1.0f / (float)m);
+        for (int k = 1; k < m; k++) sum += (T)(m - k) * cc[m - k] * a[k];
+        cc[m] = -a[m] - sum * ((T)1 / (T)m);
     }
+}
+
+// X^a and X^(1/a) of the *ss modes (src/nr/nr.cc:229-234, 252-257): exact for a = 1, 2, pow otherwise.
+__device__ __forceinline__ float ss_pow(float x, float a) { return a == 1.0f ? x : (a == 2.0f ? x * x : powf(x, a)); }
+__device__ __forceinline__ float ss_root(float x, float a) { return a == 1.0f ? x : (a == 2.0f ? sqrtf(x) : powf(x, 1.0f / a)); }
+
+// CepstralDetector<BurgCepstrumEstimator>::Process without the cepstrum estimation (src/vdet/CepstralDet.h:140-194),
+// one frame at a time, every lane of the wave in step: lane i keeps c0[i], the rest is wave-uniform.
+struct CepDetRun {
+    double c0;  // background cepstrum, coefficient `lane`
+    double dMean, dMean2, threshold;
+    int nseg;
+};
+__device__ __forceinline__ void cepdet_reset(CepDetRun &d) {
+    d.c0 = d.dMean = d.dMean2 = d.threshold = 0.0;
+    d.nseg = 0;
+}
+// cil: coefficient `lane` of the frame's cepstrum (0 beyond nc).  Returns the decision (1 = speech).
+__device__ __forceinline__ int cepdet_frame(CepDetRun &d, double cil, int lane, int nc, int ninit, double pcoef, double qcoef) {
+    int result = 0;
+    if (d.nseg == 0) d.c0 = cil;
+    else {
+        if (d.nseg == 1) d.c0 = (d.c0 + cil) / 2.0;
+        const double dl = (lane >= 1 && lane < nc) ? cil - d.c0 : 0.0;  // the first coefficient is skipped (CepstralDet.h:64-72)
+        const double dist = 4.3429 * sqrt(2 * wave_sum_fast(dl * dl));
+        if (d.nseg == 1) {
+            d.dMean = dist;
+            d.dMean2 = dist * dist;
+            d.threshold = d.dMean;
+        } else {
+            result = (d.nseg > ninit && dist >= d.threshold);
+            if (!result) {
+                d.c0 = pcoef * d.c0 + (1 - pcoef) * cil;
+                d.dMean = qcoef * d.dMean + (1 - qcoef) * dist;
+                d.dMean2 = qcoef * d.dMean2 + (1 - qcoef) * dist * dist;
+                const double dVar = d.dMean2 - d.dMean * d.dMean;
+                d.threshold = d.dMean + 2.0 * sqrt(dVar);
+            }
+        }
+    }
+    ++d.nseg;
+    return result;
 }
 
 }  // namespace

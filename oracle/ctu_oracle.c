@@ -87,6 +87,10 @@ struct ctuo {
     int do_vad;
     /* debug taps */
     double *last_power, *last_fbank;
+    /* hwss / fwss / 2fwss: what survives from file to file.  new_file() seeds the noise estimate from the spectrum vector
+     * as the previous file left it (src/nr/nr.cc:212-221,402-409; all zeros before the first file, base/types.h:35-38). */
+    double *ss_stale;   /* K: _Xsabs after the last process_frame */
+    int ss_mode;        /* 0 none, 1 hwss, 2 fwss, 3 2fwss */
 };
 
 static void set_err(ctuo_t *c, const char *msg) {
@@ -723,9 +727,13 @@ static int design_all(ctuo_t *c) {
         set_err(c, "oracle: only the spectral paths (raw PCM in; features or enhanced speech out) are restated");
         return -1;
     }
-    if (strcmp(o->nr_mode, "none") && strcmp(o->nr_mode, "exten")) {
-        set_err(c, "oracle: nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221); not restated");
-        return -1;
+    c->ss_mode = !strcmp(o->nr_mode, "hwss") ? 1 : !strcmp(o->nr_mode, "fwss") ? 2 : !strcmp(o->nr_mode, "2fwss") ? 3 : 0;
+    if (strcmp(o->nr_mode, "none") && strcmp(o->nr_mode, "exten") && !c->ss_mode) { set_err(c, "NR: Unknown noise reduction mode!"); return -1; }
+    if (c->ss_mode) { /* src/nr/nr.cc:181-442 */
+        if (!strcmp(o->vadmode, "none")) { set_err(c, "NR: Please specify Voice Activity Detector!"); return -1; } /* nr.cc:271 */
+        if (strcmp(o->vadmode, "burg")) { set_err(c, "oracle: -vad file=... reads one stream for all files and treats every byte but NUL as speech (src/nr/nr.cc:297-301); not restated"); return -1; }
+        if (o->nr_when_afterFB) { set_err(c, "NR: Cannot use Burg detector after filter bank!"); return -1; } /* nr.cc:194-195 */
+        if (c->signal_out || o->rasta) { set_err(c, "oracle: hwss/fwss/2fwss are restated on the feature path only"); return -1; }
     }
     if (o->stat_cmvn || o->apply_cmvn) {
         set_err(c, "oracle: CMVN post-processing is outside the restated path");
@@ -904,7 +912,7 @@ void ctuo_destroy(ctuo_t *c) {
     if (c->mat) { for (int i = 0; i < MAXB; i++) free(c->mat[i]); free(c->mat); }
     free(c->warp); free(c->hz); free(c->wdct); free(c->lift); free(c->WRe); free(c->trap_hamm);
     free(c->tw_re); free(c->tw_im); free(c->ut_re); free(c->ut_im);
-    free(c->last_power); free(c->last_fbank);
+    free(c->last_power); free(c->last_fbank); free(c->ss_stale);
     free(c);
 }
 
@@ -1344,6 +1352,18 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     }
     /* NR new_file, nr.cc:86-93 */
     for (int i = 0; i < K; i++) { Navg[i] = 0.95; Yavg[i] = 0.05; }
+    /* hwss / fwss / 2fwss new_file (nr.cc:212-221, 402-409): a fresh detector, the noise estimate seeded from the stale vector */
+    ctuo_cepdet_t *ss_det = NULL;
+    double *ss_nr = NULL, *ss_re = NULL, *ss_im = NULL, *ss_t = NULL, *ss_w1 = NULL, *ss_w2 = NULL;
+    int ss_ninit = o->nr_initsegs;
+    if (c->ss_mode) {
+        if (!c->ss_stale) c->ss_stale = calloc(K, sizeof(double));
+        ss_det = ctuo_cepdet_new(window, ss_ninit, o->fea_ncepcoefs, o->nr_p, o->nr_q); /* vad_init, nr.cc:263-276 */
+        ss_nr = calloc(K, sizeof(double));
+        ss_re = malloc(sizeof(double) * K); ss_im = malloc(sizeof(double) * K);
+        ss_t = malloc(sizeof(double) * wfft); ss_w1 = malloc(sizeof(double) * wfft); ss_w2 = malloc(sizeof(double) * wfft);
+        for (int i = 0; i < K; i++) Navg[i] = c->ss_mode == 3 ? c->ss_stale[i] : pow(c->ss_stale[i], o->nr_a);
+    }
     int lporder = o->fea_lporder;
     double *RRe = calloc(lporder + 2, sizeof(double)), *rc = calloc(lporder + 2, sizeof(double));
     double *a = calloc(lporder + 2, sizeof(double)), *aa = calloc(lporder + 2, sizeof(double)), *P = calloc(lporder + 2, sizeof(double));
@@ -1488,6 +1508,34 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                         else Yavg[i] = Navg[i] - nrvec[i];
                         nrvec[i] -= N;
                     }
+                }
+                if (c->ss_mode) { /* hwssNR / fwssNR / dfwssNR::process_frame, nr.cc:223-261, 331-369, 418-442 */
+                    const double aexp = o->nr_a, bsub = o->nr_b, p = o->nr_p;
+                    double *X = nrvec;
+                    if (c->ss_mode == 1) ss_ninit--;                       /* hwss counts down first (nr.cc:225) */
+                    if (c->ss_mode != 3) {                                 /* dynamic expansion */
+                        if (aexp == 2.0) for (int i = 0; i < K; i++) X[i] *= X[i];
+                        else if (aexp != 1.0) for (int i = 0; i < K; i++) X[i] = pow(X[i], aexp);
+                    }
+                    /* vad_get_frame, nr.cc:278-295: back to the time domain with the original phase, first `window` samples */
+                    for (int i = 0; i < K; i++) { ss_re[i] = X[i] * cos(Xph[i]); ss_im[i] = (i == 0 || i == K - 1) ? 0.0 : X[i] * sin(Xph[i]); }
+                    hc2r(ss_re, ss_im, wfft, ss_t, ss_w1, ss_w2);
+                    const int vad = ctuo_cepdet_process(ss_det, ss_t);
+                    if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) Navg[i] = p * Navg[i] + (1 - p) * X[i];
+                    if (c->ss_mode == 3) {
+                        for (int i = 0; i < K; i++) { X[i] -= Navg[i]; if (X[i] < 0.) X[i] = -X[i]; }
+                        if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) ss_nr[i] = p * ss_nr[i] + (1 - p) * X[i];
+                        for (int i = 0; i < K; i++) { X[i] -= ss_nr[i]; if (X[i] < 0.) X[i] = -X[i]; }
+                    } else {
+                        for (int i = 0; i < K; i++) {
+                            X[i] -= bsub * Navg[i];
+                            if (X[i] < 0.) X[i] = c->ss_mode == 1 ? 0. : -X[i];
+                        }
+                        if (aexp == 2.) for (int i = 0; i < K; i++) X[i] = sqrt(X[i]);
+                        else if (aexp != 1.) for (int i = 0; i < K; i++) X[i] = pow(X[i], 1.0 / aexp);
+                    }
+                    if (c->ss_mode != 1) ss_ninit--;
+                    memcpy(c->ss_stale, X, sizeof(double) * K);
                 }
                 if (o->fea_E && !o->fea_rawenergy) { /* _NR::compute_E, nr.cc:36-45 */
                     double E = nrvec[0] * nrvec[0] / 2. + nrvec[nrsize - 1] * nrvec[nrsize - 1] / 2.;
@@ -1736,6 +1784,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     if (is_trap && do_vad && !fail) { set_err(c, "oracle: trapdct together with VAD is not restated"); fail = 1; }
 
     free(x); free(fft_in); free(Xre); free(Xim); free(zr); free(zi); free(Xabs); free(Xph); free(Y); free(fvec);
+    ctuo_cepdet_free(ss_det); free(ss_nr); free(ss_re); free(ss_im); free(ss_t); free(ss_w1); free(ss_w2);
     free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin); free(postbuf); free(postE);
     cms_free(&cms);
     free(ola); free(ytime); free(sw1); free(sw2); free(sre); free(sim);

@@ -491,3 +491,47 @@ def test_many_ragged_utterances_walk_the_tile_chains(Engine, extra):
     assert [g.shape[0] for g in got] == frames
     for i in rng.choice(len(utts), 40, replace=False):  # the oracle is the slow side: check a random 40
         _assert_rows(got[i], orc.process(utts[i]), cfg)
+
+
+# ---- rows a10 / N4: hwss / fwss / 2fwss with the Burg cepstral detector (src/nr/nr.cc:181-442)
+SS8 = "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -vad burg".split()
+
+
+def _ss_list():
+    from ctucopy_amd import synth
+    # a list whose order matters: every file's noise estimate starts from what the previous one left behind
+    return [synth.utterance_c(synth.SET_NOISY, i, True) for i in (2, 5, 9, 12)] + [synth_utt(17, 2000, fs=8000), synth_utt(18, 120, fs=8000),
+                                                                                   synth_utt(19, 9000, fs=8000)]
+
+
+@pytest.mark.parametrize("extra", [["-nr_mode", "fwss"], ["-nr_mode", "2fwss"], ["-nr_mode", "fwss", "-nr_a", "2", "-nr_b", "1.5"],
+                                   ["-nr_mode", "hwss", "-fea_kind", "spec"], ["-nr_mode", "fwss", "-fea_kind", "logspec", "-nr_initsegs", "4"],
+                                   ["-nr_mode", "2fwss", "-nr_p", "0.9", "-nr_q", "0.95"]])
+def test_spectral_subtraction_with_burg_detector(Engine, extra):
+    cfg = SS8 + extra
+    utts = _ss_list()
+    got = Engine(cfg).extract(utts)
+    orc = Oracle(cfg)  # one instance: the stale spectrum vector survives from file to file, as in the reference's list loop
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        # the detector's decisions steer the noise estimate: a flipped frame would show as a gross error from there on
+        if "hwss" in cfg:
+            # half-wave rectification: max(X - b Navg, 0) cancels where speech is absent, and a band energy made of such bins
+            # carries err(X) X / (X - b Navg) of the fp32 spectrum: 2e-3 (no flips: the error does not grow along the file)
+            assert rel_err(g, ref) <= 2e-3, (rel_err(g, ref), " ".join(cfg))
+        else:
+            _assert_rows(g, ref, cfg + ["-nr_mode", "exten"])  # conditioning class of an NR configuration
+    # the chain is real: the same file alone (zero seed) comes out differently from its place in the list
+    alone = Engine(cfg).extract([utts[1]])[0]
+    assert not np.allclose(alone, got[1], rtol=0, atol=1e-3)
+
+
+def test_spectral_subtraction_refusals(Engine):
+    from ctucopy_amd import CtuError
+    for cfg in (C2 + ["-nr_mode", "fwss", "-vad", "burg"],                    # 16 kHz: 512-point mode
+                SS8 + ["-nr_mode", "fwss", "-fea_ncepcoefs", "10"],          # detector order tied to -fea_ncepcoefs
+                SS8 + ["-nr_mode", "hwss", "-nr_when", "afterFB"]):
+        with pytest.raises(CtuError) as ei:
+            Engine(cfg)
+        assert ei.value.code in (-1, -2)

@@ -1,0 +1,43 @@
+"""Oracle restatement of hwss / fwss / 2fwss (src/nr/nr.cc:181-442): closed forms where they exist, and the chain through
+the list (a file's noise estimate starts from the spectrum vector the previous file left behind, nr.cc:212-221).
+The detector itself is pinned against the reference's own header in tests/test_oracle_cepdet_ref.py."""
+import numpy as np
+import pytest
+
+from ctucopy_amd import synth
+from oracle.oracle import Oracle, OracleError
+
+BASE = "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -vad burg -fea_kind spec".split()
+
+
+def test_first_frame_of_the_first_file_has_a_closed_form():
+    u = synth.utterance(synth.SET_NOISY, 3, True)
+    y0 = Oracle(BASE).process(u)[0].astype(np.float64)           # band energies of frame 0 without NR
+    p, b = 0.9, 1.5
+    for mode, factor in (("fwss", abs(1 - b * (1 - p))), ("hwss", max(1 - b * (1 - p), 0.0)), ("2fwss", p * p)):
+        # seed 0 (zeroed vector before the first file): Navg_0 = (1-p) X_0, so every bin is scaled by the same factor
+        y = Oracle(BASE + ["-nr_mode", mode, "-nr_p", str(p), "-nr_b", str(b)]).process(u)[0]
+        assert np.allclose(y, factor * y0, rtol=2e-6), mode
+    y = Oracle(BASE + ["-nr_mode", "fwss", "-nr_a", "2", "-nr_p", str(p)]).process(u)[0]   # power law 2: sqrt(X^2 - (1-p) X^2)
+    assert np.allclose(y, np.sqrt(p) * y0, rtol=2e-6)
+
+
+def test_the_noise_seed_chains_the_list():
+    cfg = BASE + ["-nr_mode", "fwss"]
+    a, b = synth.utterance(synth.SET_NOISY, 1, True), synth.utterance(synth.SET_NOISY, 4, True)
+    o = Oracle(cfg)
+    ra, rb = o.process(a), o.process(b)
+    assert np.array_equal(Oracle(cfg).process(a), ra)            # first in a list = alone
+    alone = Oracle(cfg).process(b)
+    assert not np.allclose(alone[:5], rb[:5], rtol=1e-3)         # second file starts from the first file's last vector
+    o2 = Oracle(cfg)
+    o2.process(a)
+    o2.process(a[:150])                                          # a file without a frame leaves the vector untouched
+    assert np.array_equal(o2.process(b), rb)
+
+
+def test_detector_modes_the_reference_rejects():
+    with pytest.raises(OracleError, match="Voice Activity Detector"):
+        Oracle("-fs 8000 -preset mfcc -nr_mode hwss".split())
+    with pytest.raises(OracleError, match="after filter bank"):
+        Oracle("-fs 8000 -preset mfcc -nr_mode hwss -vad burg -nr_when afterFB".split())
