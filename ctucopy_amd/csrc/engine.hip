@@ -93,6 +93,7 @@ struct ctu_engine {
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
     bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
     int ss = 0;             // hwss / fwss / 2fwss (1 / 2 / 3) on frontend_kernel<..., SS>
+    std::vector<float> ss_stale;  // the spectrum vector the last file of the previous run left behind (zeros at first)
     int han_off = 0;
     bool per_wave = false;  // chains per wave (state along an utterance lives in a wave's registers)
     size_t lds_bytes = 0;
@@ -1018,6 +1019,17 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             // two or three passes.  Synchronous: each pass reads the vectors back.
             const size_t nk = (size_t)pl->n_utt * d.K;
             std::vector<float> seed(nk, 0.f), last(nk, 0.f), next(nk, 0.f);
+            if (e->ss_stale.size() != (size_t)d.K) e->ss_stale.assign(d.K, 0.f);
+            // files ahead of the first one with a frame start from what the previous run left (the reference keeps the
+            // vector for the life of the process, base/types.h:35-38, nr.cc:217-220)
+            for (int i = 0; i < pl->n_utt; i++) {
+                std::memcpy(&seed[(size_t)i * d.K], e->ss_stale.data(), d.K * sizeof(float));
+                if (pl->frames[i] > 0) break;
+            }
+            next = seed;
+            int last_live = -1;
+            for (int i = 0; i < pl->n_utt; i++)
+                if (pl->frames[i] > 0) last_live = i;
             for (int iter = 0;; iter++) {
                 HIP_TRY(hipMemcpyAsync(pl->ss_seed.p, seed.data(), nk * sizeof(float), hipMemcpyHostToDevice, s));
                 launch();
@@ -1032,6 +1044,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 if (iter > pl->n_utt) throw std::runtime_error("internal: noise seeds of the *ss chain did not settle");
                 seed = next;
             }
+            if (last_live >= 0) std::memcpy(e->ss_stale.data(), &last[(size_t)last_live * d.K], d.K * sizeof(float));
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
@@ -1380,6 +1393,12 @@ int ctu_cmvn_apply_host(ctu_engine *e, const ctu_plan *pl, float *h_rows, const 
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
     }
+}
+
+int ctu_engine_reset_chain(ctu_engine *e) {
+    if (!e) return CTU_ERR_INPUT;
+    e->ss_stale.clear();
+    return CTU_OK;
 }
 
 float ctu_engine_last_kernel_ms(ctu_engine *e) {

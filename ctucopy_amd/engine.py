@@ -31,7 +31,7 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_engine_run_host", "ctu_engine_reset_chain", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
 
@@ -73,6 +73,7 @@ def load_library():
     L.ctu_plan_total_frames.argtypes = [vp]
     L.ctu_engine_run.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_run_host.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ctu_engine_reset_chain.argtypes = [vp]
     L.ctu_engine_last_kernel_ms.restype = ctypes.c_float
     L.ctu_engine_last_kernel_ms.argtypes = [vp]
     L.ctu_cmvn_cols.argtypes = [vp]
@@ -258,6 +259,10 @@ class Engine:
         self._check(load_library().ctu_cmvn_apply(self._h, plan._h, rows.data_ptr(), spk.ctypes.data, int(n_spk),
                                                   m.ctypes.data, v.ctypes.data, s.cuda_stream))
         return rows
+
+    def reset_chain(self):
+        """hwss / fwss / 2fwss: forget the spectrum vector the previous run left behind (see include/ctu_engine.h)."""
+        self._check(load_library().ctu_engine_reset_chain(self._h))
 
     def last_kernel_ms(self):
         return float(load_library().ctu_engine_last_kernel_ms(self._h))

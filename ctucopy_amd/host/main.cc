@@ -335,6 +335,12 @@ int real_main(int argc, char **argv) {
             items.push_back(it);
         }
     }
+    // hwss / fwss / 2fwss chain the list through the noise seed (src/nr/nr.cc:212-221): one GPU, files in list order
+    const bool chained = o.nr_mode == "hwss" || o.nr_mode == "fwss" || o.nr_mode == "2fwss";
+    if (chained && ngpu > 1) {
+        if (o.verbose) std::fprintf(stderr, "ENGINE: -nr_mode %s chains the files of the list: running on one GPU\n", o.nr_mode.c_str());
+        ngpu = 1;
+    }
     // engines, one per GPU
     std::vector<const char *> cargs;
     for (auto &a : args) cargs.push_back(a.c_str());
@@ -395,6 +401,7 @@ int real_main(int argc, char **argv) {
             shard[g].push_back(i);
             load[g] += pcm[i].size();
         }
+        for (auto &sh : shard) std::sort(sh.begin(), sh.end());  // list order inside a shard
         if (signal_out) {  // speech enhancement: samples instead of rows (src/io/batch.cc:62-65,223-227)
             std::vector<std::vector<int16_t>> wav(n);
             std::vector<std::string> errs(ngpu);

@@ -103,6 +103,12 @@ int ctu_engine_run(ctu_engine *, const ctu_plan *, const int16_t *d_pcm, float *
 int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
                         int64_t *rows_per_utt);
 
+/* hwss / fwss / 2fwss (-nr_mode, with -vad burg): hwssNR::new_file seeds a file's noise estimate from the spectrum vector
+ * as the previous file left it (src/nr/nr.cc:212-221), so the list is one chain.  A run processes its utterances in plan
+ * order as that chain (synchronously: the seeds are iterated to their fixed point) and the engine keeps the last vector
+ * for the next run, as the reference keeps it for the life of the process; this call forgets it (a new process). */
+int ctu_engine_reset_chain(ctu_engine *);
+
 /* Timing of the last ctu_engine_run on this engine, measured with HIP events on the run's stream
  * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */
 float ctu_engine_last_kernel_ms(ctu_engine *);

@@ -535,3 +535,18 @@ def test_spectral_subtraction_refusals(Engine):
         with pytest.raises(CtuError) as ei:
             Engine(cfg)
         assert ei.value.code in (-1, -2)
+
+
+def test_spectral_subtraction_chain_survives_between_runs(Engine):
+    # the reference keeps the stale spectrum vector for the life of the process: a list cut into two runs is still one chain
+    cfg = SS8 + ["-nr_mode", "fwss"]
+    utts = _ss_list()
+    whole = Engine(cfg).extract(utts)
+    eng = Engine(cfg)
+    first, second = eng.extract(utts[:3]), eng.extract(utts[3:])
+    for a, b in zip(whole, first + second):
+        assert np.array_equal(a, b)
+    eng.reset_chain()
+    fresh = Engine(cfg).extract(utts[3:])
+    for a, b in zip(eng.extract(utts[3:]), fresh):
+        assert np.array_equal(a, b)
