@@ -119,6 +119,10 @@ struct ctu_plan {
     int grid = 0;               // workgroups of the front-end launch (tile chains are built for it)
     DevBuf<TileRec> tiles;
     DevBuf<int> wg_first;
+    // host-buffer runs: device copies of the arena / rows / VAD bytes, kept for the life of the plan
+    DevBuf<int16_t> h_pcm;
+    DevBuf<float> h_rows;
+    DevBuf<uint8_t> h_vad;
     DevBuf<int> tile_utt;            // utterance of every tile (SS)
     DevBuf<float> ss_seed, ss_last;  // SS: noise seeds per utterance [n_utt][K] and the vectors the utterances leave behind
     DevBuf<float2> xri;         // VAD scratch
@@ -1154,29 +1158,56 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
     return CTU_OK;
 }
 
-int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
+void *ctu_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void ctu_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+namespace {
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
                         int64_t *rows_per_utt) {
-    if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
+    if (!e || !pl_ || pl_->eng != e) return CTU_ERR_INPUT;
+    ctu_plan *pl = const_cast<ctu_plan *>(pl_);  // the device copies live in the plan
     const ctu::Design &d = *e->design;
     if (rows_per_utt)
         for (int i = 0; i < pl->n_utt; i++) rows_per_utt[i] = pl->frames[i];
     if (pl->total_frames == 0) return CTU_OK;
     try {
         HIP_TRY(hipSetDevice(e->device));
-        DevBuf<int16_t> pcm;
-        DevBuf<float> rows;
-        DevBuf<uint8_t> vad;
-        pcm.alloc((size_t)pl->total_samples);
-        rows.alloc((size_t)pl->total_frames * d.D);
-        if (e->do_vad) vad.alloc((size_t)pl->total_frames);
-        HIP_TRY(hipMemcpy(pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
-        int rc = ctu_engine_run(e, pl, pcm.p, rows.p, vad.p, nullptr);
+        // Device buffers are allocated once per plan.  Transfers: a caller buffer from ctu_host_alloc (pinned) is DMA-ed
+        // asynchronously at the link rate; pageable memory goes through the runtime's own staging (hipMemcpy).
+        if (pl->h_pcm.n < (size_t)pl->total_samples) pl->h_pcm.alloc((size_t)pl->total_samples);
+        if (pl->h_rows.n < (size_t)pl->total_frames * d.D) pl->h_rows.alloc((size_t)pl->total_frames * d.D);
+        if (e->do_vad && pl->h_vad.n < (size_t)pl->total_frames) pl->h_vad.alloc((size_t)pl->total_frames);
+        hipStream_t s = nullptr;
+        if (is_pinned(h_pcm)) HIP_TRY(hipMemcpyAsync(pl->h_pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice, s));
+        else HIP_TRY(hipMemcpy(pl->h_pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
+        int rc = ctu_engine_run(e, pl, pl->h_pcm.p, pl->h_rows.p, pl->h_vad.p, s);
         if (rc != CTU_OK) return rc;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(h_rows, rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost));
+        if (is_pinned(h_rows)) {
+            HIP_TRY(hipMemcpyAsync(h_rows, pl->h_rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(h_rows, pl->h_rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost));
+        }
         if (e->do_vad) {
             std::vector<uint8_t> v((size_t)pl->total_frames);
-            HIP_TRY(hipMemcpy(v.data(), vad.p, v.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(v.data(), pl->h_vad.p, v.size(), hipMemcpyDeviceToHost));
             if (h_vad) std::memcpy(h_vad, v.data(), v.size());
             if (d.o.vad_apply_mode == "drop") {
                 // rows of non-speech frames are dropped (src/io/batch.cc:237-238): compact each utterance in place

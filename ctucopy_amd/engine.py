@@ -31,7 +31,7 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_engine_reset_chain", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
 
@@ -74,6 +74,9 @@ def load_library():
     L.ctu_engine_run.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_run_host.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_reset_chain.argtypes = [vp]
+    L.ctu_host_alloc.restype = vp
+    L.ctu_host_alloc.argtypes = [ctypes.c_size_t]
+    L.ctu_host_free.argtypes = [vp]
     L.ctu_engine_last_kernel_ms.restype = ctypes.c_float
     L.ctu_engine_last_kernel_ms.argtypes = [vp]
     L.ctu_cmvn_cols.argtypes = [vp]
@@ -87,6 +90,33 @@ def load_library():
     L.ctu_cmvn_apply_host.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     _lib = L
     return L
+
+
+def host_alloc(shape, dtype):
+    """numpy array over page-locked host memory from ctu_host_alloc (DMA at the link rate in the *_host calls)."""
+    L = load_library()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = L.ctu_host_alloc(n)
+    if not ptr:
+        raise CtuError(CTU_ERR_DEVICE, "ctu_host_alloc failed")
+    buf = (ctypes.c_char * n).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape).view(_PinnedArray)
+    arr._owner = _Pinned(ptr)  # frees the block when the array goes away (views keep it alive through .base)
+    return arr
+
+
+class _PinnedArray(np.ndarray):
+    _owner = None
+
+
+class _Pinned:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        if self.ptr:
+            load_library().ctu_host_free(self.ptr)
+            self.ptr = None
 
 
 def _argv(args):
@@ -194,13 +224,13 @@ class Engine:
                                                   vad.data_ptr() if vad is not None else None, s.cuda_stream))
         return rows
 
-    def run_host(self, plan, arena, want_vad=False):
+    def run_host(self, plan, arena, want_vad=False, rows_out=None):
         """numpy int16 arena in, numpy float32 rows out (H2D + kernels + D2H inside the library).
 
         With want_vad: (rows, vad bytes '0'/'1' per frame, rows actually kept per utterance)."""
         arena = np.ascontiguousarray(arena, dtype=np.int16)
         assert arena.size >= plan.total_samples
-        rows = np.empty((plan.total_frames, self.dims.row_floats), dtype=np.float32)
+        rows = rows_out if rows_out is not None else np.empty((plan.total_frames, self.dims.row_floats), dtype=np.float32)
         per = np.zeros(plan.n_utt, dtype=np.int64)
         vad = np.zeros(max(plan.total_frames, 1), dtype=np.uint8)
         self._check(load_library().ctu_engine_run_host(self._h, plan._h, arena.ctypes.data, rows.ctypes.data,

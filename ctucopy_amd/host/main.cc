@@ -224,19 +224,31 @@ void run_shard(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> 
         return;
     }
     const int64_t *so = ctu_plan_sample_offsets(plan), *ro = ctu_plan_row_offsets(plan);
-    std::vector<int16_t> arena((size_t)ctu_plan_total_samples(plan), 0);
-    for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena.begin() + so[i]);
-    std::vector<float> rows((size_t)ctu_plan_total_frames(plan) * row_floats);
+    // page-locked staging for the arena and the rows: DMA at the link rate (include/ctu_engine.h, ctu_host_alloc)
+    const size_t ns_total = (size_t)ctu_plan_total_samples(plan), nr_total = (size_t)ctu_plan_total_frames(plan) * row_floats;
+    int16_t *arena = static_cast<int16_t *>(ctu_host_alloc(ns_total * sizeof(int16_t)));
+    float *rows = static_cast<float *>(ctu_host_alloc((nr_total ? nr_total : 1) * sizeof(float)));
+    if (!arena || !rows) {
+        err = "ENGINE: cannot allocate page-locked host memory";
+        ctu_host_free(arena);
+        ctu_host_free(rows);
+        ctu_plan_destroy(plan);
+        return;
+    }
+    std::memset(arena, 0, ns_total * sizeof(int16_t));
+    for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena + so[i]);
     std::vector<uint8_t> vad(has_vad ? (size_t)ctu_plan_total_frames(plan) : 0);
     std::vector<int64_t> kept(utts.size());
-    if (ctu_engine_run_host(eng, plan, arena.data(), rows.data(), has_vad ? vad.data() : nullptr, kept.data()) != CTU_OK)
+    if (ctu_engine_run_host(eng, plan, arena, rows, has_vad ? vad.data() : nullptr, kept.data()) != CTU_OK)
         err = ctu_last_error(eng);
     else
         for (size_t i = 0; i < utts.size(); i++) {
             // rows_per_utt < frames only with -vad_apply_mode drop (rows compacted in place by the library)
-            out[i].assign(rows.begin() + ro[i] * row_floats, rows.begin() + (ro[i] + kept[i]) * row_floats);
+            out[i].assign(rows + ro[i] * row_floats, rows + (ro[i] + kept[i]) * row_floats);
             if (has_vad) vad_out[i].assign(vad.begin() + ro[i], vad.begin() + ro[i + 1]);
         }
+    ctu_host_free(arena);
+    ctu_host_free(rows);
     ctu_plan_destroy(plan);
 }
 

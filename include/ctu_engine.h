@@ -27,6 +27,7 @@
 #ifndef CTU_ENGINE_H
 #define CTU_ENGINE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -97,7 +98,12 @@ int64_t ctu_plan_total_frames(const ctu_plan *);
  * stream = hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
 int ctu_engine_run(ctu_engine *, const ctu_plan *, const int16_t *d_pcm, float *d_rows, uint8_t *d_vad, void *stream);
 
-/* Host-buffer convenience: H2D, run, D2H, synchronised on return.  rows_per_utt (optional, n_utt
+/* Page-locked host memory for the host-buffer calls below: buffers from ctu_host_alloc are DMA-ed asynchronously at the
+ * link rate; any other (pageable) pointer is accepted too and goes through the runtime's staging. */
+void *ctu_host_alloc(size_t bytes);
+void ctu_host_free(void *);
+
+/* Host-buffer convenience: H2D, run, D2H, synchronised on return.  The device copies are kept in the plan.  rows_per_utt (optional, n_utt
  * entries) receives the number of rows actually produced per utterance (< frames only with
  * -vad_apply_mode drop). */
 int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
