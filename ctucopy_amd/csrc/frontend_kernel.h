@@ -25,6 +25,9 @@ namespace {
 #else
 #define STAMP(i) do { } while (0)
 #endif
+#ifndef CTU_DUAL
+#define CTU_DUAL 1      // the two passes of the 512-point mode side by side in the headline instantiation (see DUAL below)
+#endif
 #ifndef CTU_EXTEN_F64
 #define CTU_EXTEN_F64 0 // 1: exten state (Navg, Yavg) and its update in double.  Measured (tools/probes/sweep_err.py, exten_err.py): no accuracy gain - the residual is fp32 FFT noise amplified where a bin is almost fully suppressed - and -30 % throughput
 #endif
@@ -137,6 +140,111 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
 
         // ================= phase 1: frames -> power spectrum rows =================
         auto phase1 = [&] {
+        // DUAL: the two passes of the 512-point mode run side by side (slots 0-3 and 4-7 of the step in lock step): each
+        // table read serves both, and every stage offers the scheduler two independent instruction streams - the kernel
+        // is bound by dependent latency (LDS round trips, transcendental-free but long FMA chains) at four waves per SIMD,
+        // not by issue.  The plain cepstral chain only (the headline instantiation).
+        constexpr bool DUAL = CTU_DUAL && MODE == 0 && GEN == GEN_PLAIN && MD && !VX && NZ < 16;
+        if constexpr (DUAL) {
+            if (nv > 0) {
+                float2 v0[16], v1[16];
+                const int f0 = slot0 + fg, f1 = f0 + 4;
+                const int c0 = f0 < nvalid ? f0 : nvalid - 1, c1 = f1 < nvalid ? f1 : nvalid - 1;  // duplicates are never stored
+                const bool st0 = (l16 == 0) && (rec.t0 + c0 == 0), st1 = (l16 == 0) && (rec.t0 + c1 == 0);
+                {
+                    const int16_t *x0p = p.pcm + rec.sbase + (int64_t)c0 * p.wshift + 2 * l16 - 2;
+                    const int16_t *x1p = p.pcm + rec.sbase + (int64_t)c1 * p.wshift + 2 * l16 - 2;
+                    pcm4 q0[NZ], q1[NZ];
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) q0[j] = *reinterpret_cast<const pcm4 *>(x0p + 32 * j);
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) q1[j] = *reinterpret_cast<const pcm4 *>(x1p + 32 * j);
+                    float dc0 = 0.f, dc1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
+                        const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
+                        float am = (float)(int16_t)(q0[j].lo >> 16), bm = (float)(int16_t)(q1[j].lo >> 16);
+                        const float a0 = (float)(int16_t)(q0[j].hi & 0xffffu), a1 = (float)(int16_t)(q0[j].hi >> 16);
+                        const float b0 = (float)(int16_t)(q1[j].hi & 0xffffu), b1 = (float)(int16_t)(q1[j].hi >> 16);
+                        if (j == 0) {  // first sample of the file: history is 0
+                            am = st0 ? 0.f : am;
+                            bm = st1 ? 0.f : bm;
+                        }
+                        const float ya0 = w0 * (a0 - p.preem * am), ya1 = w1 * (a1 - p.preem * a0);
+                        const float yb0 = w0 * (b0 - p.preem * bm), yb1 = w1 * (b1 - p.preem * b0);
+                        v0[j] = make_float2(ya0, ya1);
+                        v1[j] = make_float2(yb0, yb1);
+                        dc0 += ya0 + ya1;
+                        dc1 += yb0 + yb1;
+                    }
+#pragma unroll
+                    for (int j = NZ; j < 16; j++) v0[j] = v1[j] = make_float2(0.f, 0.f);
+                    // mean of the windowed frame over `window` samples (src/io/in.cc:375-382); rows < NZ-1 are fully inside
+                    const float m0 = row16_allreduce_add(dc0) * p.inv_window, m1 = row16_allreduce_add(dc1) * p.inv_window;
+                    const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
+                    const float mx = ((NZ - 1) & 1) ? mk.z : mk.x, my = ((NZ - 1) & 1) ? mk.w : mk.y;
+#pragma unroll
+                    for (int j = 0; j < NZ - 1; j++) {
+                        v0[j].x -= m0;
+                        v0[j].y -= m0;
+                        v1[j].x -= m1;
+                        v1[j].y -= m1;
+                    }
+                    v0[NZ - 1].x -= m0 * mx;
+                    v0[NZ - 1].y -= m0 * my;
+                    v1[NZ - 1].x -= m1 * mx;
+                    v1[NZ - 1].y -= m1 * my;
+                }
+                dft16(v0);
+                dft16(v1);
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
+                    v0[2 * h + 1] = cmul(v0[2 * h + 1], make_float2(tw.x, tw.y));
+                    v1[2 * h + 1] = cmul(v1[2 * h + 1], make_float2(tw.x, tw.y));
+                    if (2 * h + 2 < 16) {
+                        v0[2 * h + 2] = cmul(v0[2 * h + 2], make_float2(tw.z, tw.w));
+                        v1[2 * h + 2] = cmul(v1[2 * h + 2], make_float2(tw.z, tw.w));
+                    }
+                }
+                // both transposes at once: slots 0-3 through the wave's rows 0-3, slots 4-7 through rows 4-7 (their own
+                // spectra land there afterwards)
+                wave_transpose16_dual(v0, v1, (uint32_t)(size_t)(lvoid_t *)Pw, (uint32_t)(size_t)(lvoid_t *)scratch,
+                                      Pw + 65 * l16 + 16 * fg, scratch + 65 * l16 + 16 * fg);
+                dft16(v0);
+                dft16(v1);
+                float *pr0 = Pw + fg * PSTRIDE, *pr1 = Pw + (4 + fg) * PSTRIDE;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) {
+                    const float4 u4q = ltw4[8 + (k2 >> 1)];
+                    const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
+                    const int k = l16 + 16 * k2;
+                    auto untangle = [&](const float2 (&v)[16], float *prow) {
+                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
+                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        if (l16 == 0) {
+                            br = v[(16 - k2) & 15].x;
+                            bi = v[(16 - k2) & 15].y;
+                        }
+                        const float ar = v[k2].x, ai = v[k2].y;
+                        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                        const float tr = wr * di + wi * dr;
+                        const float ti = wi * di - wr * dr;
+                        const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
+                        prow[k] = 0.25f * (ur * ur + ui * ui);
+                        prow[256 - k] = 0.25f * (vr * vr + vi * vi);
+                    };
+                    untangle(v0, pr0);
+                    untangle(v1, pr1);
+                }
+                if (l16 == 0) {  // bin 128 is its own mirror; bin 0 floor (src/io/in.cc:390)
+                    pr0[128] = v0[8].x * v0[8].x + v0[8].y * v0[8].y;
+                    pr1[128] = v1[8].x * v1[8].x + v1[8].y * v1[8].y;
+                    pr0[0] = pr1[0] = 1e-10f;
+                }
+            }
+        } else
         if (o_dbg != 2 && nv > 0) {
             const int npass = (MODE == 0 && nv > 4) ? 2 : 1;
             // the pass body is instantiated twice (it = 0, 1) so that row numbers are compile-time constants

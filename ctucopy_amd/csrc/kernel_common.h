@@ -172,6 +172,44 @@ __device__ __forceinline__ void wave_transpose16(float2 (&v)[16], uint32_t sbase
     __builtin_amdgcn_wave_barrier();
 }
 
+// Two such transposes at once (two independent sets of 16 x 16 values, scratch areas sa / sb): the stores of both go out
+// before the reads of either, so the LDS round trips overlap.
+__device__ __forceinline__ void wave_transpose16_dual(float2 (&va)[16], float2 (&vb)[16], uint32_t sa, uint32_t sb, const float *rda,
+                                                      const float *rdb) {
+    __builtin_amdgcn_wave_barrier();
+#define TR_STORE(V, C, S)                                                           \
+    lds_store_addtid<0 * 260>(V[0].C, S);   lds_store_addtid<1 * 260>(V[1].C, S);   \
+    lds_store_addtid<2 * 260>(V[2].C, S);   lds_store_addtid<3 * 260>(V[3].C, S);   \
+    lds_store_addtid<4 * 260>(V[4].C, S);   lds_store_addtid<5 * 260>(V[5].C, S);   \
+    lds_store_addtid<6 * 260>(V[6].C, S);   lds_store_addtid<7 * 260>(V[7].C, S);   \
+    lds_store_addtid<8 * 260>(V[8].C, S);   lds_store_addtid<9 * 260>(V[9].C, S);   \
+    lds_store_addtid<10 * 260>(V[10].C, S); lds_store_addtid<11 * 260>(V[11].C, S); \
+    lds_store_addtid<12 * 260>(V[12].C, S); lds_store_addtid<13 * 260>(V[13].C, S); \
+    lds_store_addtid<14 * 260>(V[14].C, S); lds_store_addtid<15 * 260>(V[15].C, S)
+    TR_STORE(va, x, sa);
+    TR_STORE(vb, x, sb);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float rea[16], reb[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) rea[n2] = rda[n2];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) reb[n2] = rdb[n2];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    TR_STORE(va, y, sa);
+    TR_STORE(vb, y, sb);
+#undef TR_STORE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) va[n2] = make_float2(rea[n2], rda[n2]);
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) vb[n2] = make_float2(reb[n2], rdb[n2]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Wave-uniform tables are read through constant-address-space pointers so that they become scalar
 // loads (s_load_dword*) into SGPRs instead of per-lane VMEM loads.
 typedef __attribute__((address_space(4))) const float cf32;
