@@ -172,7 +172,10 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (o.vadmode == "file") return "-vad file=...: one byte stream for all files, every byte but NUL counts as speech (src/nr/nr.cc:297-301)";
         if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (8 kHz, 25 ms window, -vad burg, 12 cepstral coefficients, plain chain)";
     }
-    if (o.nr_when_afterFB) return "-nr_when afterFB";
+    if (o.nr_when_afterFB) {
+        if (d.post_order > 0 || d.cms || o.stat_cmvn || o.apply_cmvn || o.do_vad() || d.signal_out) return "-nr_when afterFB together with post-processing, VAD or signal output";
+        if (d.B > 64) return "-nr_when afterFB with more than 64 bands";
+    }
     if (o.rasta) return "-nr_rasta";
     if (d.post_order > 0) {
         if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "delta / stacking on non-cepstral kinds (the reference sizes the chain as fea_ncepcoefs+1, src/fea/fea_delta.cc:22-28)";
@@ -247,7 +250,7 @@ struct Phase2Tables {
 // the plain cepstral chain: what the specialised instantiations (GEN_PLAIN / GEN_EXTEN with MD) cover
 bool plain_cepstral(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
-    return d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !d.signal_out;
+    return !o.nr_when_afterFB && d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !d.signal_out;
 }
 // Burg-cepstral VAD criterion fused into the front end (vad_fused.h): 256-point mode, 200-sample window, 14 coefficients (the preset's detector)
 bool vf_eligible(const ctu::Design &d) {
@@ -519,7 +522,7 @@ void build_tables(ctu_engine *e) {
     e->lift_off = t.lift_off;
     e->ftab.upload(t.ft);
     e->itab.upload(t.it);
-    e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS) * sizeof(float);
+    e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS + (d.o.nr_when_afterFB ? NWAVE * 128 : 0)) * sizeof(float);
     if (e->lds_bytes > 160 * 1024) throw std::runtime_error("configuration needs more than 160 KiB of LDS");
     if (d.kind == ctu::FeaKind::TrapDct) {
         std::vector<float> g(d.trap.begin(), d.trap.end());
@@ -567,7 +570,7 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     // with the VAD export, reads its flags at run time.
     const bool vx = kp.vad_export != 0;
     const int feat = e->feat;
-    const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2;
+    const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2 && !kp.nr_after_fb;
     const bool narrow = kp.CW == 16;
     if (e->ss) {
         if constexpr (MODE == 1) {
@@ -973,7 +976,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.e_mode = 0;
         if (d.o.fea_E) {  // energy routing of src/io/batch.cc:98-119
             if (d.o.fea_rawenergy) kp.e_mode = 4;
-            else if (d.kind == ctu::FeaKind::Dctc) kp.e_mode = 1;
+            else if (d.kind == ctu::FeaKind::Dctc) kp.e_mode = d.o.nr_when_afterFB ? 5 : 1;
             else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) kp.e_mode = 2;
             else kp.e_mode = 3;
         }
@@ -993,6 +996,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.fb_inld = d.o.fb_inld;
         kp.lifter_on = d.o.fea_lifter > 1;
         kp.nr_exten = d.o.nr_mode == "exten";
+        kp.nr_after_fb = d.o.nr_when_afterFB ? 1 : 0;
         kp.nr_p = (float)d.o.nr_p;
         kp.nr_p_d = d.o.nr_p;
         kp.nr_a = (float)d.o.nr_a;

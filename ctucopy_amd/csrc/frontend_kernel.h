@@ -566,7 +566,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
         // Sequential in t, independent across bins: lane = bin (bin = lane + 64 j), the step's frames in order, the
         // state (Navg, Yavg) in this wave's registers along its utterance (per-wave chains only).
-        if (o_nr_exten && nv > 0) {
+        const bool o_after_fb = FULL ? p.nr_after_fb != 0 : false;  // -nr_when afterFB: the NR runs on the band energies (phase 2)
+        if (o_nr_exten && !o_after_fb && nv > 0) {
             if (rec.t0 == 0 && slot0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
@@ -683,6 +684,12 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     esum += (double)x * x;
                 }
             }
+            if (o_e_mode == 5) {  // -nr_when afterFB: E = in->E = log(2 (P0/2 + sum P_i + P_{K-1}/2)) of the power spectrum (src/io/in.cc:404-413, batch.cc:101-104)
+                for (int k = g; k < p.K; k += 8) {
+                    const float x = prow2[k];
+                    esum += ((k == 0 || k == p.K - 1) ? 0.5 : 1.0) * (o_fb_power ? (double)x : (double)x * x);
+                }
+            }
             if (o_e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
                 for (int k = g; k < p.K; k += 8) {
                     const float x = prow2[k];
@@ -730,6 +737,44 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 acc += accb;
                 float y = acc;
                 if (o_fb_inld) y = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(y));  // pow(Y, 0.33), src/fea/fb.cc:81-83
+                if (FULL && o_after_fb && o_nr_exten) {
+                    // exten on the band energies (src/io/batch.cc:207-210; nr.cc:95-140 on fb->_Y): sequential over the step's
+                    // frames for every band, state per band in LDS (per wave: [2][64] floats behind the tables), lane (f8, g)
+                    // takes its turn when f8 comes up.  GEN_FULL only: lane = 8 f8 + g.
+                    float *st = ltw + LTW_FLOATS + wave * 128 + sl * 8 + g;  // Navg at [0], Yavg at [64]
+                    if (rec.t0 == 0 && slot0 == 0 && f8 == 0) {
+                        st[0] = 0.95f;
+                        st[64] = 0.05f;
+                    }
+                    for (int i = 0; i < nv; i++) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (f8 == i && bidx >= 0) {
+                            const float na = st[0], ya = st[64];
+                            float H, omH;
+                            if (p.nr_a == 1.0f) {
+                                const float ir = __builtin_amdgcn_rcpf(na + ya);
+                                H = na * ir;
+                                omH = ya * ir;
+                            } else if (p.nr_a == 2.0f) {
+                                const float r2 = na * na + ya * ya;
+                                const float ir = __builtin_amdgcn_rsqf(r2);
+                                const float r = r2 * ir;
+                                H = na * ir;
+                                omH = (ya * ya) * __builtin_amdgcn_rcpf(r * (r + na));
+                            } else {
+                                H = na / powf(powf(na, p.nr_a) + powf(ya, p.nr_a), 1.0f / p.nr_a);
+                                omH = 1.0f - H;
+                            }
+                            const float nn = p.nr_p * na + (1.0f - p.nr_p) * (H * y);
+                            st[0] = nn;
+                            st[64] = fabsf(y - nn);
+                            y *= omH;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 if (o_e_mode == 3 && bidx >= 0)  // band energy of the FB output, i.e. after its ^0.33 (src/fea/fea_impl.cc:44-50,68-74)
                     esum += ((bidx == 0 || bidx == p.B - 1) ? 0.5 : 1.0) * ((double)y * y);
                 // v_log_f32 (log2, ~1 ulp) * ln 2: band energies of int16 speech are far from the denormal range
@@ -756,7 +801,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             STAMP(8);  // filter bank + per-band accumulation
             if (o_e_mode && !(FEAT == FEAT_BANDS && p.band_to_scratch)) {
                 float e = 0.f;
-                if (o_e_mode == 1 || o_e_mode == 3) e = (float)log(2.0 * lanes8_allreduce_add(esum));
+                if (o_e_mode == 1 || o_e_mode == 3 || o_e_mode == 5) e = (float)log(2.0 * lanes8_allreduce_add(esum));
                 else if (o_e_mode == 4) e = (float)log(lanes8_allreduce_add(esum));
                 if (o_e_mode != 2 && fvalid && g == 0) p.rows[(rbase + fslot) * p.D + p.e_slot] = e;
             }

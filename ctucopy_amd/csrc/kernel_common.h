@@ -65,6 +65,7 @@ struct KParams {
     float nr_p, nr_a;
     unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
     int skip_phase2;  // signal output (row N3): spectra are exported, nothing is projected
+    int nr_after_fb;  // -nr_when afterFB: exten runs on the band energies inside phase 2 (GEN_FULL)
     int per_wave;     // chains per wave (wg_first has grid * NWAVE entries) instead of per workgroup
     int am_off;       // MD instantiations: A operands of the DCT MFMAs [2 * NS][64] in the LDS tables
     double nr_p_d;    // exten smoothing constant in double

@@ -18,6 +18,8 @@ ap.add_argument("--cfg", default="C3")
 ap.add_argument("--utts", type=int, default=2000)
 ap.add_argument("--steps", type=int, default=5)
 a = ap.parse_args()
+if a.cfg == "C4_10k":  # configs[3] at the size of the benchmark's list: 10 000 utterances of S-NOISY
+    a.cfg, a.utts = "C4", 10000
 cfg = CFGS[a.cfg]
 eng = Engine(cfg)
 fs = eng.dims.fs
