@@ -36,6 +36,7 @@
 #include "vad_fused.h"
 #include "frontend_kernel.h"
 #include "trap_kernel.h"
+#include "decode_kernels.h"
 
 namespace {
 
@@ -1428,6 +1429,21 @@ int ctu_cmvn_apply_host(ctu_engine *e, const ctu_plan *pl, float *h_rows, const 
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
     }
+}
+
+int ctu_decode_g711(ctu_engine *e, const uint8_t *d_codes, int64_t n, int alaw, int16_t *d_pcm, void *stream) {
+    if (!e || n < 0 || (n && (!d_codes || !d_pcm))) return CTU_ERR_INPUT;
+    if (n == 0) return CTU_OK;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        const int grid = (int)std::min<int64_t>((n / 8 + 255) / 256, (int64_t)e->n_cu * 8);
+        hipLaunchKernelGGL(g711_kernel, dim3(std::max(grid, 1)), dim3(256), 0, (hipStream_t)stream, d_codes, d_pcm, n, alaw);
+        HIP_TRY(hipGetLastError());
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        return CTU_ERR_DEVICE;
+    }
+    return CTU_OK;
 }
 
 int ctu_engine_reset_chain(ctu_engine *e) {

@@ -109,6 +109,11 @@ void ctu_host_free(void *);
 int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
                         int64_t *rows_per_utt);
 
+/* -format_in alaw | mulaw on the device: n G.711 codes -> n int16 samples, the expansion of src/io/amulaw.h:20-53
+ * (alaw2lin, called from src/io/in.cc:481-560) bit for bit.  The caller lays the codes of an utterance at the same offsets
+ * as its samples (ctu_plan_sample_offsets) and may decode the whole arena at once.  Asynchronous on `stream`. */
+int ctu_decode_g711(ctu_engine *, const uint8_t *d_codes, int64_t n, int alaw, int16_t *d_pcm, void *stream);
+
 /* hwss / fwss / 2fwss (-nr_mode, with -vad burg): hwssNR::new_file seeds a file's noise estimate from the spectrum vector
  * as the previous file left it (src/nr/nr.cc:212-221), so the list is one chain.  A run processes its utterances in plan
  * order as that chain (synchronously: the seeds are iterated to their fixed point) and the engine keeps the last vector

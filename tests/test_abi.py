@@ -24,8 +24,11 @@ def _built():
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ctu_engine.h")).read()
-    declared = set(re.findall(r"\b(ctu_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(ctu_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(ceng.EXPORTS)
+    synth_hdr = open(os.path.join(ROOT, "include", "ctu_synth.h")).read()
+    declared |= set(re.findall(r"\b(ctu_synth_[a-z0-9_]+)\s*\(", synth_hdr))
+    assert {"ctu_synth_length", "ctu_synth_fill", "ctu_synth_fill_arena"} <= declared
     lib = ctypes.CDLL(cbuild.LIB)
     for name in declared:
         assert hasattr(lib, name), name

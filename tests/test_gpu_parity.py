@@ -569,3 +569,25 @@ def test_noise_reduction_after_the_filter_bank(Engine, cfg):
         ref = orc.process(u)
         assert g.shape == ref.shape and np.isfinite(g).all()
         _assert_rows(g, ref, cfg)
+
+
+def test_g711_decode_on_the_device_matches_the_reference_table(Engine):
+    import ctypes
+    import os
+    import torch
+    ref_so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_amulaw.so")
+    if not os.path.exists(ref_so):
+        pytest.skip("oracle/_ref/libref_amulaw.so not built")
+    eng = Engine(C2)
+    rng = np.random.default_rng(4)
+    for alaw in (True, False):
+        table = np.zeros(256, dtype=np.int16)
+        ctypes.CDLL(ref_so).ref_amulaw_table(1 if alaw else 0, table.ctypes.data_as(ctypes.c_void_p))
+        for n in (256, 8191, 100003):
+            codes = np.arange(256, dtype=np.uint8) if n == 256 else rng.integers(0, 256, n, dtype=np.uint8)
+            got = eng.decode_g711(torch.from_numpy(codes).cuda(), alaw=alaw).cpu().numpy()
+            assert np.array_equal(got, table[codes])
+        # an unaligned view takes the scalar tail path
+        codes = rng.integers(0, 256, 4099, dtype=np.uint8)
+        dev = torch.from_numpy(codes).cuda()
+        assert np.array_equal(eng.decode_g711(dev[3:], alaw=alaw).cpu().numpy(), table[codes[3:]])
