@@ -16,7 +16,7 @@ cfg, f = sys.argv[1], sys.argv[2]
 for r in csv.DictReader(open(f)):
     n = r["Name"]
     if any(k in n for k in ("frontend_kernel", "post_kernel", "cms_", "vad_", "trapdct", "synth_kernel", "ola_kernel", "cmvn_")):
-        short = n.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         print('"%s","%s","%s","%.0f","%s","%s"' % (cfg, short, r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
 PY
   tail -1 $O/$c.log | cut -c1-160
