@@ -93,6 +93,7 @@ struct ctu_engine {
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
     bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
+    bool sy = false;        // speech-enhancement output with the inverse transform inside the front end (frontend_kernel<..., SY>)
     int ss = 0;             // hwss / fwss / 2fwss (1 / 2 / 3) on frontend_kernel<..., SS>
     std::vector<float> ss_stale;  // the spectrum vector the last file of the previous run left behind (zeros at first)
     int han_off = 0;
@@ -247,6 +248,9 @@ struct Phase2Tables {
 #endif
 #ifndef CTU_VF
 #define CTU_VF 1
+#endif
+#ifndef CTU_SY
+#define CTU_SY 1  // 0: speech-enhancement output through the exported spectra and synth_kernel (round 1's path)
 #endif
 // the plain cepstral chain: what the specialised instantiations (GEN_PLAIN / GEN_EXTEN with MD) cover
 bool plain_cepstral(const ctu::Design &d) {
@@ -504,6 +508,7 @@ void build_tables(ctu_engine *e) {
         e->lds_bytes = ((size_t)TILE * PSTRIDE + LTW_FLOATS) * sizeof(float);
         e->feat = FEAT_BANDS;
         e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;
+        e->sy = CTU_SY;
         return;
     }
     Phase2Tables t;
@@ -573,7 +578,10 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const int feat = e->feat;
     const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2 && !kp.nr_after_fb;
     const bool narrow = kp.CW == 16;
-    if (e->ss) {
+    if (e->sy && kp.skip_phase2) {
+        launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, false, true>, grid, s, kp);
+    }
+    else if (e->ss) {
         if constexpr (MODE == 1) {
             if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
             else if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, 1, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
@@ -890,8 +898,10 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
         if (d.signal_out) {
-            pl->xri.alloc((size_t)ro * d.K);
-            pl->pnr.alloc((size_t)ro * d.K);
+            if (!e->sy) {
+                pl->xri.alloc((size_t)ro * d.K);
+                pl->pnr.alloc((size_t)ro * d.K);
+            }
             pl->utt_info.upload(uinfo);
             std::vector<long long> so64(pl->sample_off.begin(), pl->sample_off.end());
             pl->d_sample_off.upload(so64);
@@ -946,7 +956,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.band_log = d.kind != ctu::FeaKind::Spec;
         kp.band_to_scratch = d.kind == ctu::FeaKind::TrapDct;
         kp.lp_is_lpa = d.kind == ctu::FeaKind::Lpa;
-        kp.vad_export = signal ? 1 : ((!e->do_vad || e->vf) ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0)));
+        kp.ybuf = pl->ybuf.p;
+        kp.syn_scale = 1.0f / (float)d.wfft;
+        kp.vad_export = (signal && !e->sy) ? 1 : ((!e->do_vad || e->vf || signal) ? 0 : (e->vp.cri == 1 ? 1 : (e->vp.cri == 0 ? 2 : 0)));
         kp.vad_ci = pl->vad_ci.p;
         kp.vad_nc = e->vp.ncoef;
         kp.ss_mode = e->ss;
@@ -1357,7 +1369,7 @@ int ctu_engine_run_signal(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pc
         sp.K = d.K; sp.wfft = d.wfft; sp.window = d.window; sp.wshift = d.wshift;
         sp.inv_n = 1.0f / (float)d.wfft;
         sp.corr = d.ola_corr;
-        if (pl->total_frames > 0) {
+        if (pl->total_frames > 0 && !e->sy) {
             const int g = (int)std::min<int64_t>((pl->total_frames + 7) / 8, (int64_t)e->n_cu * 8);
             hipLaunchKernelGGL(synth_kernel, dim3(g), dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->ybuf.p, (long long)pl->total_frames, sp);
             HIP_TRY(hipGetLastError());

@@ -57,16 +57,20 @@ namespace {
 // SS:     spectral subtraction with the Burg cepstral detector (hwss / fwss / 2fwss, src/nr/nr.cc:181-442; 256-point
 //         mode): the detector sees the frames rebuilt from the (expanded) spectra, so a step runs phase 1 twice - once to
 //         feed the detector, whose transposes and frames use up the P rows, once more for the subtraction itself.
-template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false>
+// SY:     speech-enhancement output (row N3, sigOUT src/io/out.cc:405-434): the step's spectra after NR go back to the time
+//         domain in registers (the inverse of vad_fused.h with the synthesis conventions) and the frames are written for
+//         the overlap-add kernel; no spectra through HBM, no phase 2.
+template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false, bool SY = false>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL;
     static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
     static_assert(!VF || (MODE == 1 && !VX), "VF: 256-point mode, no spectrum export");
     static_assert(!SS || (MODE == 1 && !VX && !VF && GEN == GEN_PLAIN), "SS: 256-point mode, plain chain");
+    static_assert(!SY || (!VX && !VF && !SS && GEN == GEN_FULL), "SY: run-time flags, no export");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
-    const bool o_skip_phase2 = FULL ? p.skip_phase2 != 0 : false;
+    const bool o_skip_phase2 = SY ? true : (FULL ? p.skip_phase2 != 0 : false);
     const bool per_wave = (GEN == GEN_EXTEN || FULL || VF || SS) ? p.per_wave != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
@@ -136,10 +140,12 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // this step's frame slots are [slot0, slot0 + 8) of the tile; their spectra live in the wave's P rows 0..7
         const int slot0 = per_wave ? sub * 8 : wave * 8;
         const int nv = min(max(nvalid - slot0, 0), 8);
-        float2 vz[16];  // VF: the forward transform's output Z[l16 + 16 r], kept for the inverse
+        float2 vz[16];   // VF / SS / SY: the forward transform's output Z[l16 + 16 r], kept for the inverse
+        float2 vz1[16];  // SY, 512-point mode: the same of the second pass
 
         // ================= phase 1: frames -> power spectrum rows =================
-        auto phase1 = [&] {
+        // `which`: bit 0 = first pass (slots 0-3; the only pass of the 256-point mode), bit 1 = second pass (slots 4-7)
+        auto phase1 = [&](int which) {
         // DUAL: the two passes of the 512-point mode run side by side (slots 0-3 and 4-7 of the step in lock step): each
         // table read serves both, and every stage offers the scheduler two independent instruction streams - the kernel
         // is bound by dependent latency (LDS round trips, transcendental-free but long FMA chains) at four waves per SIMD,
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const int16_t *xb = p.pcm + rec.sbase + (int64_t)cb_ * p.wshift + l16;
                     const bool start_a = (l16 == 0) && (rec.t0 + ca == 0), start_b = (l16 == 0) && (rec.t0 + cb_ == 0);
                     float dca = 0.f, dcb = 0.f;
-#pragma unroll
+    #pragma unroll
                     for (int j = 0; j < NZ; j++) {
                         const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];
                         const float w = (j & 1) ? w4.z : w4.x;  // 0 beyond the window
@@ -278,12 +284,12 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         dca += ya;
                         dcb += yb;
                     }
-#pragma unroll
+    #pragma unroll
                     for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
                     STAMP(1);
                     if (o_remove_dc) {
                         const float ma = row16_allreduce_add(dca) * p.inv_window, mb = row16_allreduce_add(dcb) * p.inv_window;
-#pragma unroll
+    #pragma unroll
                         for (int j = 0; j < NZ; j++) {
                             const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
                             const float mm = (j & 1) ? mk.z : mk.x;
@@ -296,9 +302,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     pcm4 q[NZ];
                     // samples x[i0-2 .. i0+1] of row j of this lane's frame: i0 = 32 j + 2 l16
                     const int16_t *x = p.pcm + rec.sbase + (int64_t)fc * p.wshift + 2 * l16 - 2;
-#pragma unroll
+    #pragma unroll
                     for (int j = 0; j < NZ; j++) q[j] = *reinterpret_cast<const pcm4 *>(x + 32 * j);
-#pragma unroll
+    #pragma unroll
                     for (int j = 0; j < NZ; j++) {
                         const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
                         const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
@@ -311,14 +317,14 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         v[j] = make_float2(y0, y1);
                         dc += y0 + y1;
                     }
-#pragma unroll
+    #pragma unroll
                     for (int j = NZ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
                     STAMP(1);  // PCM + window loads, convert, pre-emphasis, window
                     if (o_remove_dc) {
                         // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
                         const float m = row16_allreduce_add(dc) * p.inv_window;
                         if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
-#pragma unroll
+    #pragma unroll
                             for (int j = 0; j < 16; j++) {
                                 const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
                                 v[j].x -= m * ((j & 1) ? mk.z : mk.x);
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                             }
                         } else {  // exact instantiation: rows < NZ-1 are fully inside the window
                             const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
-#pragma unroll
+    #pragma unroll
                             for (int j = 0; j < NZ - 1; j++) {
                                 v[j].x -= m;
                                 v[j].y -= m;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 // ---- stage 1: DFT16 over n1 (registers), lane = n2; then twiddle W256^(n2*k1)
                 dft16(v);
                 __builtin_amdgcn_sched_barrier(0);  // twiddles: fetch them just in time, not across the DFT
-#pragma unroll
+    #pragma unroll
                 for (int h = 0; h < 8; h++) {
                     const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
                     v[2 * h + 1] = cmul(v[2 * h + 1], make_float2(tw.x, tw.y));
@@ -355,9 +361,12 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 // ---- stage 2: DFT16 over n2, lane = k1: v[k2] = Z[k1 + 16 k2]
                 dft16(v);
                 STAMP(5);  // DFT16 #2
-                if constexpr (VF || SS) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) vz[r] = v[r];
+                if constexpr (VF || SS || SY) {
+    #pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        if (it == 0) vz[r] = v[r];
+                        else vz1[r] = v[r];
+                    }
                 }
 
                 if constexpr (MODE == 1) {
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     // bins 0..128 of both; the mirror bin comes from lane (16-k1)%16 as in MODE 0
                     const int fa = slot0 + 2 * fg;
                     float *pa = Pw + (2 * fg) * PSTRIDE, *pb = pa + PSTRIDE;
-#pragma unroll
+    #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) {
                         if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);
                         float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     //      each together with its mirror bin 256-k held by lane (16-k1)%16 in register 15-k2
                     //      (register (16-k2)%16 for k1 = 0).
                     float *prow = Pw + (it * 4 + fg) * PSTRIDE;
-#pragma unroll
+    #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) {
                         if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // two batches: bounds the registers in flight
                         const float4 u4q = ltw4[8 + (k2 >> 1)];
@@ -433,13 +442,14 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
                 STAMP(6);  // untangle + P writes
             };
-            pass(std::integral_constant<int, 0>{});
-            if (npass == 2) pass(std::integral_constant<int, 1>{});
+            if (which & 1) pass(std::integral_constant<int, 0>{});
+            if (npass == 2 && (which & 2)) pass(std::integral_constant<int, 1>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         };
-        phase1();
+        constexpr bool SY_HALVES = SY && MODE == 0;  // pass, NR and synthesis per half step: one transform output live at a time
+        if constexpr (!SY_HALVES) phase1(3);
         // The step's eight time-domain frames rebuilt from the P rows (magnitudes) and vz (directions), then the Burg
         // cepstra of each (vad_fused.h).  Uses up the wave's P rows.  out[x]: lane 16 fg + i holds coefficient i of frame
         // slot 2 fg + x.  HANN: the detector of the *ss modes windows the frame first (src/vdet/CepstralDet.h:131-147).
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     vbits |= (unsigned)cepdet_frame(sdet, cil, lane, SS_NC, p.ss_init, p.nr_p_d, p.ss_q) << s_;
                 }
                 // (3) the spectra again, then the subtraction proper, frames in order, lane = bin
-                phase1();
+                phase1(3);
                 const float pp = p.nr_p, qq = 1.0f - p.nr_p;
                 for (int f = 0; f < nv; f++) {
                     const int t = rec.t0 + slot0 + f;
@@ -553,22 +563,26 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         }
 
 
-        if (!o_fb_power && nv > 0) {  // magnitude instead of power (src/io/in.cc:415-417); off the default path
-            for (int e = lane; e < nv * p.K; e += 64) {
-                const int f = e / p.K, k = e - f * p.K;
-                float *q_ = Pw + f * PSTRIDE + k;
-                *q_ = sqrtf(*q_);
+        // magnitude instead of power (src/io/in.cc:415-417), rows [r0, r1); off the default path
+        auto to_magnitude = [&](int r0, int r1) {
+            if (!o_fb_power && r1 > r0) {
+                for (int e = lane + r0 * p.K; e < r1 * p.K; e += 64) {
+                    const int f = e / p.K, k = e - f * p.K;
+                    float *q_ = Pw + f * PSTRIDE + k;
+                    *q_ = sqrtf(*q_);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+        };
 
         // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
         // Sequential in t, independent across bins: lane = bin (bin = lane + 64 j), the step's frames in order, the
         // state (Navg, Yavg) in this wave's registers along its utterance (per-wave chains only).
         const bool o_after_fb = FULL ? p.nr_after_fb != 0 : false;  // -nr_when afterFB: the NR runs on the band energies (phase 2)
-        if (o_nr_exten && !o_after_fb && nv > 0) {
-            if (rec.t0 == 0 && slot0 == 0) {  // new file: Navg = 0.95, Yavg = 0.05
+        auto apply_exten = [&](int f_lo, int f_hi) {
+        if (o_nr_exten && !o_after_fb && f_hi > f_lo) {
+            if (rec.t0 == 0 && slot0 == 0 && f_lo == 0) {  // new file: Navg = 0.95, Yavg = 0.05
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     navg[j] = (xstate_t)0.95;
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             const xstate_t pp = (xstate_t)p.nr_p_d, qq = (xstate_t)1.0 - pp;
-            for (int f = 0; f < nv; f++) {
+            for (int f = f_lo; f < f_hi; f++) {
                 float *row = Pw + f * PSTRIDE + lane;
                 float X[NJ];
 #pragma unroll
@@ -643,6 +657,66 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+        };
+        if constexpr (!SY_HALVES) {
+            to_magnitude(0, SY ? 8 : nv);  // SY: all rows - a duplicate frame shares a complex transform with a real one
+            apply_exten(0, nv);
+        }
+        // ================= speech synthesis (row N3): spectra after NR -> time-domain frames =================
+        if constexpr (SY) {
+            if (nv > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if constexpr (MODE == 1) {
+                    const uint32_t sb = (uint32_t)(size_t)(lvoid_t *)scratch;
+                    const float *srd = scratch + 65 * l16 + 16 * fg;
+                    float2 vn[16];
+                    vf_scale_spectra<true>(vz, vn, Pw + (2 * fg) * PSTRIDE, Pw + (2 * fg + 1) * PSTRIDE, l16, partner, p.syn_scale);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();  // every lane has its magnitudes before the scratch (P rows 4-7) is reused
+                    vf_inverse_fft(vn, ltw4, sb, srd);
+                    const int fa = slot0 + 2 * fg;
+                    float *ya = p.ybuf + (rbase + fa) * p.window + l16, *yb = ya + p.window;
+#pragma unroll
+                    for (int m = 0; m < 16; m++) {
+                        if (l16 + 16 * m < p.window) {
+                            if (fa < nvalid) ya[16 * m] = vn[m].x;
+                            if (fa + 1 < nvalid) yb[16 * m] = vn[m].y;
+                        }
+                    }
+                } else {
+                    // each pass inverts through its own (spent) P rows: slots 0-3 in rows 0-3, slots 4-7 in rows 4-7
+                    auto synth = [&](const float2 (&vzz)[16], auto HALF) {
+                        constexpr int half = decltype(HALF)::value;
+                        float2 vn[16];
+                        float *rows4 = Pw + 4 * half * PSTRIDE;
+                        vf_scale_tangle0(vzz, vn, rows4 + fg * PSTRIDE, ltw4, l16, partner, 2.f * p.syn_scale);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        vf_inverse_fft(vn, ltw4, (uint32_t)(size_t)(lvoid_t *)rows4, rows4 + 65 * l16 + 16 * fg);
+                        // z[n] = x[2n] + i x[2n+1], n = l16 + 16 m: float2 stores (the window is even)
+                        const int fr = slot0 + 4 * half + fg;
+                        float2 *y = reinterpret_cast<float2 *>(p.ybuf + (rbase + fr) * p.window) + l16;
+#pragma unroll
+                        for (int m = 0; m < 16; m++)
+                            if (2 * (l16 + 16 * m) < p.window && fr < nvalid) y[16 * m] = vn[m];
+                    };
+                    const int n0 = nv < 4 ? nv : 4;
+                    phase1(1);
+                    to_magnitude(0, 4);
+                    apply_exten(0, n0);
+                    synth(vz, std::integral_constant<int, 0>{});
+                    if (nv > 4) {
+                        phase1(2);
+                        to_magnitude(4, 8);
+                        apply_exten(4, nv);
+                        synth(vz1, std::integral_constant<int, 1>{});
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         if (VX && p.vad_export && nv > 0) {  // the VAD looks at in->_Xsabs after NR (src/io/batch.cc:230-240, src/vad/vad.cc:96-107,227-230)
             if (p.vad_export == 1) {

@@ -81,6 +81,8 @@ struct KParams {
     const float *ss_seed;
     float *ss_last;
     const int *tile_utt;
+    float *ybuf;      // SY instantiations: time-domain frames [total_frames][window] ahead of the overlap-add
+    float syn_scale;  // SY: 1 / wfft (sigOUT's amplitude factor, src/io/out.cc:416-422)
     uint8_t *vad_out; // VF instantiations: the VAD bytes ('0' / '1' per frame), written by the wave that walks the utterance
     VadParams vad;    // VF instantiations: the decision replay's parameters
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
@@ -131,12 +133,17 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 }
 
 // LDS store of one dword per lane at  M0 + OFF + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
-// what the transpose below writes (16 k1-rows of [frame slot][n2]).  M0 is set in the same statement; nothing else in
-// this kernel depends on M0.
+// what the transposes write (16 k1-rows of [frame slot][n2]).  M0 is compiler-reserved (it may hold an offset of the
+// compiler's own, e.g. for register spills) and an asm statement's write to it is invisible to the compiler: the
+// statement saves and restores it.  One wait state between the SALU write of M0 and an LDS add-TID instruction (ISA
+// manual, required software nops).
 template <int OFF>
 __device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
-    // one wait state between the SALU write of M0 and an LDS add-TID instruction (ISA manual, required software nops)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" ::"v"(v), "s"(base), "n"(OFF) : "memory");
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v), "s"(base), "n"(OFF)
+                 : "memory");
 }
 
 // Transpose of 16 x 16 complex values between "lane" and "register" inside each 16-lane group of a wave, through an LDS
@@ -145,6 +152,7 @@ __device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
 // n2, n2 = 0..15, with immediate offsets: banks (k1 + 16 fg + n2) mod 32, distinct over each half wave.
 //   sbase = LDS byte address of the scratch (wave-uniform), rd = scratch + 65 * (lane & 15) + 16 * (lane >> 4).
 __device__ __forceinline__ void wave_transpose16(float2 (&v)[16], uint32_t sbase, const float *rd) {
+    sbase = __builtin_amdgcn_readfirstlane(sbase);  // wave-uniform by construction; this makes it provably so ("s" operand)
     __builtin_amdgcn_wave_barrier();
 #define TR_STORE(C)                                                                         \
     lds_store_addtid<0 * 260>(v[0].C, sbase);   lds_store_addtid<1 * 260>(v[1].C, sbase);   \
@@ -177,6 +185,8 @@ __device__ __forceinline__ void wave_transpose16(float2 (&v)[16], uint32_t sbase
 // before the reads of either, so the LDS round trips overlap.
 __device__ __forceinline__ void wave_transpose16_dual(float2 (&va)[16], float2 (&vb)[16], uint32_t sa, uint32_t sb, const float *rda,
                                                       const float *rdb) {
+    sa = __builtin_amdgcn_readfirstlane(sa);
+    sb = __builtin_amdgcn_readfirstlane(sb);
     __builtin_amdgcn_wave_barrier();
 #define TR_STORE(V, C, S)                                                           \
     lds_store_addtid<0 * 260>(V[0].C, S);   lds_store_addtid<1 * 260>(V[1].C, S);   \

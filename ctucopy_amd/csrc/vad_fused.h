@@ -31,8 +31,11 @@ constexpr int VF_FSTRIDE = 216;   // floats per time-domain frame in the LDS sta
 //   XA'[k] = gA XA[k], XB'[k] = gB XB[k], g = Xsabs_after_NR / |X|  (bins 1..127; DC and Nyquist are real, see below)
 //   Z'[k] = XA'[k] + i XB'[k] = hA (sr, si) + hB (dr, di),  h = g / 2,  (sr, si, dr, di) the untangle sums of Z[k], Z[256-k]
 // and the same with the mirror's gains for k > 128 (Hermitian extension).
+// SYN: speech synthesis (sigOUT, src/io/out.cc:405-427) instead of the detector's frame: magnitudes times `scale` (1/N),
+// DC and Nyquist as positive reals (the reference stores them before its sign fix-up, out.cc:416-419).
+template <bool SYN = false>
 __device__ __forceinline__ void vf_scale_spectra(const float2 (&vz)[16], float2 (&vn)[16], const float *rowA, const float *rowB,
-                                                 int l16, int partner) {
+                                                 int l16, int partner, float scale = 1.f) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - r].x)));
@@ -42,7 +45,7 @@ __device__ __forceinline__ void vf_scale_spectra(const float2 (&vz)[16], float2 
             bi = vz[(16 - r) & 15].y;
         }
         const int k = l16 + 16 * r, kt = r < 8 ? k : 256 - k;  // kt <= 128: where the gains live
-        const float pa = rowA[kt], pb = rowB[kt];             // Xsabs after NR
+        const float pa = SYN ? rowA[kt] * scale : rowA[kt], pb = SYN ? rowB[kt] * scale : rowB[kt];  // Xsabs after NR
         const float ar = vz[r].x, ai = vz[r].y;
         const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
         const float ma = sr * sr + si * si, mb = dr * dr + di * di;  // 4 |XA|^2, 4 |XB|^2
@@ -59,12 +62,73 @@ __device__ __forceinline__ void vf_scale_spectra(const float2 (&vz)[16], float2 
         if (l16 == 0 && (r == 0 || r == 8)) {
             // DC: phase 0; Nyquist: 0 or pi by the sign of the real part (src/io/in.cc:398-399); both purely real.
             // Z[0] = XA[0] + i XB[0] and Z[128] likewise, with XA, XB real there.
-            xar = r == 0 ? pa : (ar >= 0.f ? pa : -pa);
+            xar = (r == 0 || SYN) ? pa : (ar >= 0.f ? pa : -pa);
             xai = 0.f;
-            xbr = r == 0 ? pb : (ai >= 0.f ? pb : -pb);
+            xbr = (r == 0 || SYN) ? pb : (ai >= 0.f ? pb : -pb);
             xbi = 0.f;
         }
         vn[r] = make_float2(xar - xbi, xai + xbr);
+    }
+}
+
+// Stage A of the 512-point mode (one real frame per 16-lane group, packed as z[n] = x[2n] + i x[2n+1]):
+// vz[r] = Z[l16 + 16 r].  The forward untangle gives u = 2 X[k] and v with X[256-k] = conj(v) / 2 for the lane's bins
+// k = l16 + 16 k2 and their mirrors; both are re-scaled to the magnitudes in `row` (times `scale`) and tangled back:
+//   s' = (u' + v') / 2,  t' = (u' - v') / 2,  d' = i conj(w) t',  Z'[k] = (s' + d') / 2,  Z'[256-k] = conj((s' - d') / 2)
+// The second one belongs to the mirror lane's register 15 - k2 and is exchanged by ds_bpermute (lane 0 owns its mirrors).
+// Synthesis conventions only (SYN): DC, Nyquist (bin 256) as positive reals.  HC2R's x = 2 * IDFT_256-sum(Z'): `scale`
+// carries that 2.
+__device__ __forceinline__ void vf_scale_tangle0(const float2 (&vz)[16], float2 (&vn)[16], const float *row, const float4 *ltw4, int l16,
+                                                 int partner, float scale) {
+    float2 bp[8];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const float4 u4q = ltw4[8 + (k2 >> 1)];
+        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - k2].x)));
+        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - k2].y)));
+        if (l16 == 0) {
+            br = vz[(16 - k2) & 15].x;
+            bi = vz[(16 - k2) & 15].y;
+        }
+        const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
+        const float ar = vz[k2].x, ai = vz[k2].y;
+        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+        const float tr = wr * di + wi * dr, ti = wi * di - wr * dr;
+        const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
+        const int k = l16 + 16 * k2;
+        const float tk = row[k] * scale, tm = row[256 - k] * scale;
+        const float mu = ur * ur + ui * ui, mv = vr * vr + vi * vi;  // 4 |X[k]|^2, 4 |X[256-k]|^2
+        float iu = __builtin_amdgcn_rsqf(mu), iv = __builtin_amdgcn_rsqf(mv);
+        iu = iu * (1.5f - 0.5f * mu * iu * iu);
+        iv = iv * (1.5f - 0.5f * mv * iv * iv);
+        const float gu = 2.f * tk * iu, gv = 2.f * tm * iv;   // u' = 2 X'[k] = 2 tk u / |u|
+        float upr = gu * ur, upi = gu * ui, vpr = gv * vr, vpi = gv * vi;
+        if (!(mu > 0.f)) { upr = 0.f; upi = -2.f * tk; }      // c_ph(0, 0) = -pi/2: X' = -i t
+        if (!(mv > 0.f)) { vpr = 0.f; vpi = 2.f * tm; }       // v' = conj(2 X'[256-k])
+        if (l16 == 0 && k2 == 0) {                             // bins 0 and 256: positive reals
+            upr = 2.f * tk; upi = 0.f;
+            vpr = 2.f * tm; vpi = 0.f;
+        }
+        const float spr = 0.5f * (upr + vpr), spi = 0.5f * (upi + vpi), tpr = 0.5f * (upr - vpr), tpi = 0.5f * (upi - vpi);
+        const float dpr = wi * tpr - wr * tpi, dpi = wr * tpr + wi * tpi;   // i conj(w) t'
+        vn[k2] = make_float2(0.5f * (spr + dpr), 0.5f * (spi + dpi));
+        bp[k2] = make_float2(0.5f * (spr - dpr), -0.5f * (spi - dpi));
+    }
+    // bin 128 (lane 0, register 8): X[128] = conj(Z[128]), so Z'[128] = g Z[128]
+    float2 z128;
+    {
+        const float m = vz[8].x * vz[8].x + vz[8].y * vz[8].y, t = row[128] * scale * 0.5f;  // Z' carries half of HC2R's 2 here: see below
+        float im = __builtin_amdgcn_rsqf(m);
+        im = im * (1.5f - 0.5f * m * im * im);
+        // |X[128]| = |Z[128]|; the factor 2 of `scale` belongs to the u / v convention (u = 2X): here X' = tgt X / |X| directly
+        z128 = m > 0.f ? make_float2(2.f * t * im * vz[8].x, 2.f * t * im * vz[8].y) : make_float2(0.f, 2.f * t);
+    }
+#pragma unroll
+    for (int r = 8; r < 16; r++) {
+        const float orr = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(bp[15 - r].x)));
+        const float ori = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(bp[15 - r].y)));
+        const float2 l0 = r == 8 ? z128 : bp[(16 - r) & 7];
+        vn[r] = l16 == 0 ? l0 : make_float2(orr, ori);
     }
 }
 
@@ -101,6 +165,9 @@ __device__ __forceinline__ void vf_inverse_fft(float2 (&vn)[16], const float4 *l
 // T = float (the VAD module's criterion: identical decisions to the double oracle on every test recording) or double
 // (the *ss modes' detector: it sees spectra raised to the power a, whose frames are nearly sinusoidal - reflection
 // coefficients within 1e-6 of +-1 - and a float lattice then loses the cepstra's digits that the threshold test needs).
+#ifndef CTU_BURG_DREC
+#define CTU_BURG_DREC 0  // 1: the denominator of order m+1 from that of order m, D' = (1 - k^2) D - f[m]^2 - b[N-1]^2, instead of the sum
+#endif
 template <int NC, int JW, class T>
 __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
     T ef[VF_SPL], eb[VF_SPL];
@@ -130,6 +197,7 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l
     };
     clear_last();
     T a[NC];
+    T den_next = 0;
 #pragma unroll
     for (int i = 0; i < NC; i++) a[i] = i == 0 ? (T)1 : (T)0;
 #pragma unroll
@@ -138,22 +206,27 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l
             if (ik - 1 < VF_SPL) ef[ik - 1] = lane0 ? (T)0 : ef[ik - 1];
             if (ik >= 2 && ik - 2 < VF_SPL) eb[ik - 2] = lane0 ? (T)0 : eb[ik - 2];
             const T eb_prev = dpp_mov<0x121>(eb[VF_SPL - 1]);  // row_ror:1
+            constexpr bool DREC = CTU_BURG_DREC && sizeof(T) == 4 && JW >= 0;
             T n0 = 0, n1 = 0, d0 = 0, d1 = 0;
 #pragma unroll
             for (int j = 0; j < VF_SPL; j++) {
                 const T bm = j == 0 ? eb_prev : eb[j - 1];
                 if (j & 1) {
                     n1 += ef[j] * bm;
-                    d1 += ef[j] * ef[j];
-                    d1 += bm * bm;
+                    if (!DREC || ik == 1) {
+                        d1 += ef[j] * ef[j];
+                        d1 += bm * bm;
+                    }
                 } else {
                     n0 += ef[j] * bm;
-                    d0 += ef[j] * ef[j];
-                    d0 += bm * bm;
+                    if (!DREC || ik == 1) {
+                        d0 += ef[j] * ef[j];
+                        d0 += bm * bm;
+                    }
                 }
             }
             const T num = row_sum(n0 + n1);
-            const T den = row_sum(d0 + d1);
+            const T den = (!DREC || ik == 1) ? row_sum(d0 + d1) : den_next;
             const T rc = -((T)2 * num) / den;
             alpha *= (T)1 - rc * rc;
             T carry = eb_prev;
@@ -164,6 +237,12 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l
                 const T nef = ef[j] + rc * bm, neb = bm + rc * ef[j];
                 ef[j] = nef;
                 eb[j] = neb;
+            }
+            if constexpr (DREC) {
+                // sample ik's forward error (lane 0, or lane 1's first register) and the window's last backward error
+                const T fe = ik < VF_SPL ? (lane0 ? ef[ik < VF_SPL ? ik : 0] : (T)0) : (l16 == 1 ? ef[0] : (T)0);
+                const T be = lanew ? eb[JW] : (T)0;
+                den_next = ((T)1 - rc * rc) * den - row_sum(fe * fe + be * be);
             }
             clear_last();
             T an[NC];
