@@ -227,8 +227,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
                     const int k = l16 + 16 * k2;
                     auto untangle = [&](const float2 (&v)[16], float *prow) {
-                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
-                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        float br = mirror_fetch(v[15 - k2].x, partner);
+                        float bi = mirror_fetch(v[15 - k2].y, partner);
                         if (l16 == 0) {
                             br = v[(16 - k2) & 15].x;
                             bi = v[(16 - k2) & 15].y;
@@ -377,8 +377,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) {
                         if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
-                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        float br = mirror_fetch(v[15 - k2].x, partner);
+                        float bi = mirror_fetch(v[15 - k2].y, partner);
                         if (l16 == 0) {
                             br = v[(16 - k2) & 15].x;
                             bi = v[(16 - k2) & 15].y;
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     for (int k2 = 0; k2 < 8; k2++) {
                         if ((k2 & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // two batches: bounds the registers in flight
                         const float4 u4q = ltw4[8 + (k2 >> 1)];
-                        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].x)));
-                        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[15 - k2].y)));
+                        float br = mirror_fetch(v[15 - k2].x, partner);
+                        float bi = mirror_fetch(v[15 - k2].y, partner);
                         if (l16 == 0) {
                             br = v[(16 - k2) & 15].x;
                             bi = v[(16 - k2) & 15].y;

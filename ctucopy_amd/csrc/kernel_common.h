@@ -132,19 +132,27 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k = 0; k < 16; k++) v[k] = t[k];
 }
 
-// LDS store of one dword per lane at  M0 + OFF + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
-// what the transposes write (16 k1-rows of [frame slot][n2]).  M0 is compiler-reserved (it may hold an offset of the
-// compiler's own, e.g. for register spills) and an asm statement's write to it is invisible to the compiler: the
-// statement saves and restores it.  One wait state between the SALU write of M0 and an LDS add-TID instruction (ISA
-// manual, required software nops).
-template <int OFF>
-__device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(v), "s"(base), "n"(OFF)
-                 : "memory");
-}
+// LDS stores of one dword per lane at  M0 + offset + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
+// what the transposes write (16 k1-rows of [frame slot][n2], 260 bytes apart).  M0 is compiler-reserved (it may hold an
+// offset of the compiler's own, e.g. for register spills) and an asm statement's write to it is invisible to the compiler:
+// the statement saves M0, writes the 16 rows and restores it.  One wait state between the SALU write of M0 and an LDS
+// add-TID instruction (ISA manual, required software nops).
+#define CTU_ADDTID16(V, C, BASE)                                                                                                     \
+    do {                                                                                                                             \
+        uint32_t keep_;                                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"                                                         \
+                     "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:260\n\tds_write_addtid_b32 %3 offset:520\n\t"  \
+                     "ds_write_addtid_b32 %4 offset:780\n\tds_write_addtid_b32 %5 offset:1040\n\tds_write_addtid_b32 %6 offset:1300\n\t" \
+                     "ds_write_addtid_b32 %7 offset:1560\n\tds_write_addtid_b32 %8 offset:1820\n\tds_write_addtid_b32 %9 offset:2080\n\t" \
+                     "ds_write_addtid_b32 %10 offset:2340\n\tds_write_addtid_b32 %11 offset:2600\n\tds_write_addtid_b32 %12 offset:2860\n\t" \
+                     "ds_write_addtid_b32 %13 offset:3120\n\tds_write_addtid_b32 %14 offset:3380\n\tds_write_addtid_b32 %15 offset:3640\n\t" \
+                     "ds_write_addtid_b32 %16 offset:3900\n\ts_mov_b32 m0, %0"                                                        \
+                     : "=&s"(keep_)                                                                                                  \
+                     : "v"(V[0].C), "v"(V[1].C), "v"(V[2].C), "v"(V[3].C), "v"(V[4].C), "v"(V[5].C), "v"(V[6].C), "v"(V[7].C),      \
+                       "v"(V[8].C), "v"(V[9].C), "v"(V[10].C), "v"(V[11].C), "v"(V[12].C), "v"(V[13].C), "v"(V[14].C),              \
+                       "v"(V[15].C), "s"(BASE)                                                                                      \
+                     : "memory");                                                                                                    \
+    } while (0)
 
 // Transpose of 16 x 16 complex values between "lane" and "register" inside each 16-lane group of a wave, through an LDS
 // scratch of 16 x 65 dwords (re, then im): element (k1, n2) of group fg sits at dword 65 k1 + 16 fg + n2 = 65 k1 + lane.
@@ -154,16 +162,7 @@ __device__ __forceinline__ void lds_store_addtid(float v, uint32_t base) {
 __device__ __forceinline__ void wave_transpose16(float2 (&v)[16], uint32_t sbase, const float *rd) {
     sbase = __builtin_amdgcn_readfirstlane(sbase);  // wave-uniform by construction; this makes it provably so ("s" operand)
     __builtin_amdgcn_wave_barrier();
-#define TR_STORE(C)                                                                         \
-    lds_store_addtid<0 * 260>(v[0].C, sbase);   lds_store_addtid<1 * 260>(v[1].C, sbase);   \
-    lds_store_addtid<2 * 260>(v[2].C, sbase);   lds_store_addtid<3 * 260>(v[3].C, sbase);   \
-    lds_store_addtid<4 * 260>(v[4].C, sbase);   lds_store_addtid<5 * 260>(v[5].C, sbase);   \
-    lds_store_addtid<6 * 260>(v[6].C, sbase);   lds_store_addtid<7 * 260>(v[7].C, sbase);   \
-    lds_store_addtid<8 * 260>(v[8].C, sbase);   lds_store_addtid<9 * 260>(v[9].C, sbase);   \
-    lds_store_addtid<10 * 260>(v[10].C, sbase); lds_store_addtid<11 * 260>(v[11].C, sbase); \
-    lds_store_addtid<12 * 260>(v[12].C, sbase); lds_store_addtid<13 * 260>(v[13].C, sbase); \
-    lds_store_addtid<14 * 260>(v[14].C, sbase); lds_store_addtid<15 * 260>(v[15].C, sbase)
-    TR_STORE(x);
+    CTU_ADDTID16(v, x, sbase);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float re[16];
@@ -171,8 +170,7 @@ __device__ __forceinline__ void wave_transpose16(float2 (&v)[16], uint32_t sbase
     for (int n2 = 0; n2 < 16; n2++) re[n2] = rd[n2];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    TR_STORE(y);
-#undef TR_STORE
+    CTU_ADDTID16(v, y, sbase);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -188,17 +186,8 @@ __device__ __forceinline__ void wave_transpose16_dual(float2 (&va)[16], float2 (
     sa = __builtin_amdgcn_readfirstlane(sa);
     sb = __builtin_amdgcn_readfirstlane(sb);
     __builtin_amdgcn_wave_barrier();
-#define TR_STORE(V, C, S)                                                           \
-    lds_store_addtid<0 * 260>(V[0].C, S);   lds_store_addtid<1 * 260>(V[1].C, S);   \
-    lds_store_addtid<2 * 260>(V[2].C, S);   lds_store_addtid<3 * 260>(V[3].C, S);   \
-    lds_store_addtid<4 * 260>(V[4].C, S);   lds_store_addtid<5 * 260>(V[5].C, S);   \
-    lds_store_addtid<6 * 260>(V[6].C, S);   lds_store_addtid<7 * 260>(V[7].C, S);   \
-    lds_store_addtid<8 * 260>(V[8].C, S);   lds_store_addtid<9 * 260>(V[9].C, S);   \
-    lds_store_addtid<10 * 260>(V[10].C, S); lds_store_addtid<11 * 260>(V[11].C, S); \
-    lds_store_addtid<12 * 260>(V[12].C, S); lds_store_addtid<13 * 260>(V[13].C, S); \
-    lds_store_addtid<14 * 260>(V[14].C, S); lds_store_addtid<15 * 260>(V[15].C, S)
-    TR_STORE(va, x, sa);
-    TR_STORE(vb, x, sb);
+    CTU_ADDTID16(va, x, sa);
+    CTU_ADDTID16(vb, x, sb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float rea[16], reb[16];
@@ -208,9 +197,8 @@ __device__ __forceinline__ void wave_transpose16_dual(float2 (&va)[16], float2 (
     for (int n2 = 0; n2 < 16; n2++) reb[n2] = rdb[n2];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    TR_STORE(va, y, sa);
-    TR_STORE(vb, y, sb);
-#undef TR_STORE
+    CTU_ADDTID16(va, y, sa);
+    CTU_ADDTID16(vb, y, sb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -255,6 +243,20 @@ __device__ __forceinline__ float lanes8_allreduce_add(float x) {
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// The mirror-bin partner of the untangle steps: lane l of a 16-lane row reads lane (16 - l) & 15.  CTU_DPPMIRROR = 1:
+// row_mirror then row_ror:1 on the VALU (lane l <- mirror lane l-1 = original lane 16-l), no LDS crossbar cycles;
+// 0: ds_bpermute (`partner` = byte address of the source lane).
+#ifndef CTU_DPPMIRROR
+#define CTU_DPPMIRROR 0
+#endif
+__device__ __forceinline__ float mirror_fetch(float x, int partner) {
+#if CTU_DPPMIRROR
+    (void)partner;
+    return dpp_mov<0x121>(dpp_mov<0x140>(x));
+#else
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(x)));
+#endif
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {

@@ -38,8 +38,8 @@ __device__ __forceinline__ void vf_scale_spectra(const float2 (&vz)[16], float2 
                                                  int l16, int partner, float scale = 1.f) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - r].x)));
-        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - r].y)));
+        float br = mirror_fetch(vz[15 - r].x, partner);
+        float bi = mirror_fetch(vz[15 - r].y, partner);
         if (l16 == 0) {  // lane 0 holds its own mirrors: bin 16 r <-> bin 16 (16 - r)
             br = vz[(16 - r) & 15].x;
             bi = vz[(16 - r) & 15].y;
@@ -84,8 +84,8 @@ __device__ __forceinline__ void vf_scale_tangle0(const float2 (&vz)[16], float2 
 #pragma unroll
     for (int k2 = 0; k2 < 8; k2++) {
         const float4 u4q = ltw4[8 + (k2 >> 1)];
-        float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - k2].x)));
-        float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(vz[15 - k2].y)));
+        float br = mirror_fetch(vz[15 - k2].x, partner);
+        float bi = mirror_fetch(vz[15 - k2].y, partner);
         if (l16 == 0) {
             br = vz[(16 - k2) & 15].x;
             bi = vz[(16 - k2) & 15].y;
@@ -125,8 +125,8 @@ __device__ __forceinline__ void vf_scale_tangle0(const float2 (&vz)[16], float2 
     }
 #pragma unroll
     for (int r = 8; r < 16; r++) {
-        const float orr = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(bp[15 - r].x)));
-        const float ori = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(bp[15 - r].y)));
+        const float orr = mirror_fetch(bp[15 - r].x, partner);
+        const float ori = mirror_fetch(bp[15 - r].y, partner);
         const float2 l0 = r == 8 ? z128 : bp[(16 - r) & 7];
         vn[r] = l16 == 0 ? l0 : make_float2(orr, ori);
     }
