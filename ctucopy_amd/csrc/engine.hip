@@ -90,7 +90,7 @@ struct ctu_engine {
     int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
     DevBuf<float> lanec, ftab, trapG;
     DevBuf<int> itab;
-    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, cfd_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
     bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
     bool sy = false;        // speech-enhancement output with the inverse transform inside the front end (frontend_kernel<..., SY>)
@@ -221,7 +221,6 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
-        if (!o.fb_inld) return "LP analysis without -fb_inld: the autocorrelation of squared band energies spans the whole float range and the normal equations need fp64 throughout (PLP, which compresses with ^0.33, is on the path)";
         if (o.fea_lporder >= d.B) return "LP order not below the number of bands: the normal equations are singular and the reference's output is rounding noise";
         if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above the in-register limit";
     }
@@ -238,7 +237,7 @@ struct Phase2Tables {
     std::vector<float> ft;   // LDS image followed by the lifter
     std::vector<int> it;     // slot_chunk[NS+1] | row_slot[nfea]
     std::vector<int> cells, slot_chunk;
-    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, am_off = 0, han_off = 0, NS = 0, CW = 4, ncoef_out = 0;
+    int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, cfd_off = 0, am_off = 0, han_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;  // lane map of the MFMA tail: lane = frame + 8 h + 16 kk, group = kk + 4 h
 };
 
@@ -297,6 +296,9 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
     std::vector<int> cell(NS * 8 * 2, 0);   // {first bin of the chunk run, band index or -1}
     const int CWS = CW + 4;  // row stride: 20 or 28 floats = 5 or 7 16-byte units, distinct mod 16 over the 8 groups
     std::vector<float> cf((size_t)NS * 8 * CWS, 0.f);
+    // LP analysis on uncompressed band energies (no -fb_inld): the same rows in double for the double tail (FEAT_LPD)
+    const bool lpd = (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) && !d.o.fb_inld;
+    std::vector<double> cfd(lpd ? (size_t)NS * 8 * CW : 0, 0.0);
     // DCTC: coefficient row r of a cell is the value written to output slot r (c1..cN, then c0)
     std::vector<int> coef_of_slot;
     if (d.kind == ctu::FeaKind::Dctc) {
@@ -383,6 +385,7 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
             for (int i = 0; i < ncoef; i++) {
                 const int src = (d.kind == ctu::FeaKind::Dctc) ? coef_of_slot[i] : i;
                 if (src >= 0) cf[((size_t)sl * 8 + g) * CWS + i] = (float)(*coef_tab)[(size_t)src * B + b];
+                if (src >= 0 && lpd) cfd[((size_t)sl * 8 + g) * CW + i] = (*coef_tab)[(size_t)src * B + b];
             }
         }
         for (int ch = 0; ch < nch; ch++)
@@ -426,6 +429,16 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
                     if (b >= 0 && m < t.ncoef_out && coef_of_slot[m] >= 0) v = (float)(*coef_tab)[(size_t)coef_of_slot[m] * B + b];
                     ft.push_back(v);
                 }
+    }
+    if (lpd) {
+        t.cfd_off = (int)ft.size();  // a multiple of 4 floats: 8-byte aligned in LDS
+        for (double v : cfd) {
+            float h[2];
+            std::memcpy(h, &v, 8);
+            ft.push_back(h[0]);
+            ft.push_back(h[1]);
+        }
+        while (ft.size() & 3) ft.push_back(0.f);
     }
     if (ss_eligible(d)) {
         // Hann window of the *ss modes' detector, han[i] = 0.5 (1 - cos(2 * 3.141592653 / window * i)) (src/vdet/CepstralDet.h:133-136)
@@ -517,6 +530,7 @@ void build_tables(ctu_engine *e) {
     e->ncoef_out = t.ncoef_out;
     e->ck_off = t.ck_off;
     e->cf_off = t.cf_off;
+    e->cfd_off = t.cfd_off;
     e->am_off = t.am_off;
     e->md = t.md;
     e->vf = vf_eligible(d);
@@ -540,7 +554,7 @@ void build_tables(ctu_engine *e) {
         case ctu::FeaKind::TrapDct: e->feat = FEAT_BANDS; break;
         case ctu::FeaKind::Dctc: e->feat = FEAT_DCTC; break;
         case ctu::FeaKind::Lpc:
-        case ctu::FeaKind::Lpa: e->feat = FEAT_LP; break;
+        case ctu::FeaKind::Lpa: e->feat = d.o.fb_inld ? FEAT_LP : FEAT_LPD; break;
         case ctu::FeaKind::None: e->feat = FEAT_BANDS; break;  // not reached: the signal path returns above
     }
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
@@ -564,6 +578,12 @@ void launch_nz(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, VX, 16, GEN>, grid, s, kp);
     else if (feat == FEAT_DCTC && !wide) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, VX, 16, GEN>, grid, s, kp);
     else if (feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, VX, MAXC, GEN>, grid, s, kp);
+    else if (feat == FEAT_LPD) {
+        if constexpr (GEN == GEN_FULL) {
+            if (!wide) launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, VX, 16, GEN_FULL>, grid, s, kp);
+            else launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, VX, MAXC, GEN_FULL>, grid, s, kp);
+        } else throw std::runtime_error("internal: the double LP tail has run-time flags only");
+    }
     else if (!wide) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, VX, 16, GEN>, grid, s, kp);
     else launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, VX, MAXC, GEN>, grid, s, kp);
 }
@@ -602,7 +622,7 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
         else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true>, grid, s, kp);
     }
     else if (vx) launch_nz<NZ, MODE, true, GEN_FULL>(e, grid, s, kp);
-    else if (base && !kp.fb_inld && !kp.nr_exten) launch_nz<NZ, MODE, false, GEN_PLAIN>(e, grid, s, kp);
+    else if (base && !kp.fb_inld && !kp.nr_exten && feat != FEAT_LPD) launch_nz<NZ, MODE, false, GEN_PLAIN>(e, grid, s, kp);
     else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP && kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa)
         // the PLP preset exactly: order and number of cepstra fixed at compile time (LPO)
         launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12>, grid, s, kp);
@@ -980,6 +1000,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.tab_floats = e->tab_floats;
         kp.ck_off = e->ck_off;
         kp.cf_off = e->cf_off;
+        kp.cfd_off = e->cfd_off;
         kp.NS = e->NS;
         kp.CW = e->CW;
         kp.ncoef_out = e->ncoef_out;

@@ -746,9 +746,16 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             const int fslot = slot0 + f8;
             const bool fvalid = f8 < nv;
             const float *prow2 = Pw + f8 * PSTRIDE;
-            float c[NC];
+            // FEAT_LPD: LP analysis on uncompressed band energies (no -fb_inld).  The autocorrelation values of a squared
+            // spectrum are nearly equal and the normal equations ill-conditioned: fp32 sums and recursions lose everything
+            // (1e-2 .. NaN against a double tail on the same band energies), while the result is insensitive to the 1e-6
+            // relative noise of the fp32 band energies themselves.  Accumulation, Levinson-Durbin and a -> c run in double.
+            constexpr bool LPD = FEAT == FEAT_LPD;
+            constexpr bool IS_LP = FEAT == FEAT_LP || LPD;
+            typedef std::conditional_t<LPD, double, float> lp_t;
+            lp_t c[NC];
 #pragma unroll
-            for (int i = 0; i < NC; i++) c[i] = 0.f;
+            for (int i = 0; i < NC; i++) c[i] = 0;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             double esum = 0.0;  // -fea_E sums squares of values that may already be powers: beyond the float range on silent frames
             if (o_e_mode == 4) {  // raw energy: sum of x[i]^2, i = 1..window-1 (src/io/in.cc:353-361); rare, read from HBM
@@ -860,15 +867,20 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 } else {
                     if (FEAT == FEAT_LP && !o_fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
-                    if constexpr (MD) {
+                    if constexpr (LPD) {
+                        const double yd = o_fb_inld ? (double)y : (double)y * (double)y;
+                        cell_accumulate<NC>(c, reinterpret_cast<const double *>(ltab + p.cfd_off) + (sl * 8 + g) * NC, yd);
+                    } else if constexpr (MD) {
                         // D[m][n] += sum_kk A[m][kk] B[kk][n]: B = this slot's band logarithms as they stand (n = lane & 15,
                         // kk = lane >> 4); A = DCT rows of the bands in groups kk (columns n < 8) or kk + 4 (columns n >= 8)
                         const float a0 = ltab[p.am_off + (2 * sl) * 64 + lane], a1 = ltab[p.am_off + (2 * sl + 1) * 64 + lane];
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, y, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, y, acc1, 0, 0, 0);
                     } else {
-                        const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
-                        cell_accumulate<NC>(c, cf, y);
+                        if constexpr (!LPD) {
+                            const float4 *cf = reinterpret_cast<const float4 *>(ltab + p.cf_off + (sl * 8 + g) * (NC + 4));  // +4: bank spread
+                            cell_accumulate<NC>(c, cf, y);
+                        }
                     }
                 }
             }
@@ -891,7 +903,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     for (int r = 0; r < 4; r++)
                         if (4 * (lane >> 4) + r < p.ncoef_out) orow[r] = o4[r];
                 }
-            } else if (FEAT == FEAT_DCTC || FEAT == FEAT_LP) {
+            } else if (FEAT == FEAT_DCTC || IS_LP) {
                 cells_reduce<NC>(c);
                 float *orow = p.rows + (rbase + fslot) * p.D;
                 if (FEAT == FEAT_DCTC) {
@@ -914,23 +926,23 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     // conditioned; measured deviation from a double recursion ~1e-6 (tests/test_gpu_parity.py::test_c3_plp)
                     constexpr int PM = LPO ? LPO : MAX_LP;
                     const int P_ = LPO ? LPO : p.lporder, ncep_ = LPO ? LPO : p.ncep;
-                    float a[PM + 1], cc[PM + 1];
-                    const float r0 = c[0];
-                    if (o_e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = __builtin_amdgcn_logf(r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
-                    float rc = -c[1] / r0;
-                    float err = r0 * (1 - rc * rc);
+                    lp_t a[PM + 1], cc[PM + 1];
+                    const lp_t r0 = c[0];
+                    if (o_e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = LPD ? (float)log((double)r0) : __builtin_amdgcn_logf((float)r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
+                    lp_t rc = -c[1] / r0;
+                    lp_t err = r0 * (1 - rc * rc);
                     a[0] = 1;
                     a[1] = rc;
 #pragma unroll
                     for (int ik = 2; ik <= PM; ik++) {
                         if (ik <= P_ && ik < NC) {  // the host picks NC > lporder
-                            float dm = c[ik < NC ? ik : NC - 1];
+                            lp_t dm = c[ik < NC ? ik : NC - 1];
 #pragma unroll
                             for (int n = 1; n < ik; n++) dm += a[n] * c[ik - n];
                             rc = -dm / err;
 #pragma unroll
                             for (int n = 1; n <= ik / 2; n++) {
-                                const float lo = a[n], hi = a[ik - n];
+                                const lp_t lo = a[n], hi = a[ik - n];
                                 a[n] = lo + rc * hi;
                                 if (n != ik - n) a[ik - n] = hi + rc * lo;
                             }
@@ -941,24 +953,24 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     if (p.lp_is_lpa) {
 #pragma unroll
                         for (int i = 1; i <= PM; i++)
-                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = a[i];
+                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = (float)a[i];
                     } else {
-                        cc[0] = __builtin_amdgcn_logf(err) * 0.69314718056f;
+                        cc[0] = LPD ? (lp_t)log((double)err) : (lp_t)(__builtin_amdgcn_logf((float)err) * 0.69314718056f);
 #pragma unroll
                         for (int n = 1; n <= PM; n++) {
                             if (n <= ncep_) {
-                                float sum = 0;
+                                lp_t sum = 0;
 #pragma unroll
                                 for (int k = 1; k < n; k++)
-                                    if (k <= P_) sum += (float)(n - k) * cc[n - k] * a[k];
-                                cc[n] = (n <= P_ ? -a[n] : 0.0f) - sum / (float)n;
+                                    if (k <= P_) sum += (lp_t)(n - k) * cc[n - k] * a[k];
+                                cc[n] = (n <= P_ ? -a[n] : (lp_t)0) - sum / (lp_t)n;
                             }
                         }
 #pragma unroll
                         for (int n = 0; n <= PM; n++) {
                             if (n <= ncep_) {
-                                float val = cc[n];
-                                if (n >= 1 && p.lifter_on) val *= ftab[p.lift_off + n - 1];
+                                float val = (float)cc[n];
+                                if (n >= 1 && p.lifter_on) val = (float)(cc[n] * (lp_t)ftab[p.lift_off + n - 1]);
                                 const int slot = row_slot[n];
                                 if (slot >= 0 && fvalid && g == (n & 7)) orow[slot] = val;
                             }

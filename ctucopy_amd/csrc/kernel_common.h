@@ -27,7 +27,7 @@ constexpr int LTW_STRIDE = 116, LTW_FLOATS = 16 * LTW_STRIDE;
 
 // Kernel variants by feature tail.  BANDS covers spec / logspec / the log-mel scratch of TRAP (runtime flags
 // band_log, band_to_scratch); LP covers lpc and lpa (runtime flag lp_is_lpa).
-enum FeatMode { FEAT_BANDS = 0, FEAT_DCTC = 2, FEAT_LP = 3 };
+enum FeatMode { FEAT_BANDS = 0, FEAT_DCTC = 2, FEAT_LP = 3, FEAT_LPD = 4 };  // LPD: LP analysis with the autocorrelation and the recursions in double
 
 // VAD module parameters (src/vad/vad.cc, src/vad/vad.h; used by vad_kernels.h and by the fused path of the front end)
 struct VadParams {
@@ -56,6 +56,7 @@ struct KParams {
     // LDS tables (float index): chunk weights float4 [NC][8] at 0 | cell {first bin, band index or -1} (int2)
     // [NS][8] at ck_off | per-cell coefficient rows [NS][8][CW] at cf_off
     int tab_floats, ck_off, cf_off, NS, CW;
+    int cfd_off;                // FEAT_LPD: per-cell coefficient rows in double, [NS][8][CW] doubles (8-byte aligned)
     int ncoef_out;              // DCTC: coefficients written per row (table rows are in output order)
     int e_mode, e_slot, K, window;  // -fea_E: 0 none, 1 spectrum (nr->E), 2 log R[0], 3 band energy, 4 raw frame energy
     int wshift, B, nfea, D, ncep, lporder;
@@ -290,6 +291,16 @@ __device__ __forceinline__ void cell_accumulate(float (&c)[NCW], const float4 *c
         c[4 * i + 2] += k4[i].z * y;
         c[4 * i + 3] += k4[i].w * y;
     }
+}
+template <int NCW>
+__device__ __forceinline__ void cell_accumulate(double (&c)[NCW], const double *cf, double y) {
+#pragma unroll
+    for (int i = 0; i < NCW; i++) c[i] += cf[i] * y;
+}
+template <int NCW>
+__device__ __forceinline__ void cells_reduce(double (&c)[NCW]) {
+#pragma unroll
+    for (int i = 0; i < NCW; i++) c[i] = lanes8_allreduce_add(c[i]);
 }
 template <int NCW>
 __device__ __forceinline__ void cells_reduce(float (&c)[NCW]) {

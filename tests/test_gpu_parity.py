@@ -113,6 +113,18 @@ def test_c3_plp(Engine):
     _check(Engine, C3 + ["-fea_ncepcoefs", "16", "-fea_lporder", "10"], [synth_utt(43, 16000)])
 
 
+def test_lp_on_uncompressed_bands(Engine):
+    # LP analysis without -fb_inld (src/fea/fea_impl.cc:165-169 squares the band energies): the autocorrelation and the
+    # recursions run in double on the device (FEAT_LPD); PLP's filter bank with the law switched off, a mel bank, lpa, 8 kHz
+    base = "-fs 16000 -format_in raw -format_out htk -preem 0.97".split()
+    mel = base + "-fb_scale mel -fb_shape triang -fb_norm off -fb_power on -fb_eqld off -fb_inld off -fb_definition 26filters".split()
+    _check(Engine, mel + "-fea_kind lpc -fea_lporder 12 -fea_ncepcoefs 12".split(), [sig("CS0")[:40000], synth_utt(44, 24000)])
+    _check(Engine, mel + "-fea_kind lpa -fea_lporder 10 -fea_ncepcoefs 10".split(), [synth_utt(45, 16000)])
+    _check(Engine, mel + "-fea_kind lpc -fea_lporder 14 -fea_ncepcoefs 16 -fea_E on".split(), [synth_utt(46, 16000)])
+    _check(Engine, C3 + ["-fb_inld", "off"], [sig("CS3")[:40000], synth_utt(47, 20000)])
+    _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset plpc -fb_inld off".split(), [sig("CS3")[:30000]])
+
+
 def test_exten_16k(Engine):
     cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
     _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
