@@ -125,6 +125,15 @@ struct ctu_plan {
     DevBuf<int16_t> h_pcm;
     DevBuf<float> h_rows;
     DevBuf<uint8_t> h_vad;
+    // host-buffer runs of large batches: consecutive utterance ranges as plans of their own, run on two streams so that
+    // the upload of one range overlaps the kernels and the download of the previous one (ctu_engine_run_host)
+    std::vector<std::unique_ptr<ctu_plan>> parts;
+    std::vector<int> part_first;       // first utterance of every part, n_utt at the end
+    hipStream_t part_stream[2] = {nullptr, nullptr};
+    ~ctu_plan() {
+        for (hipStream_t st : part_stream)
+            if (st) (void)hipStreamDestroy(st);
+    }
     DevBuf<int> tile_utt;            // utterance of every tile (SS)
     DevBuf<float> ss_seed, ss_last;  // SS: noise seeds per utterance [n_utt][K] and the vectors the utterances leave behind
     DevBuf<float2> xri;         // VAD scratch
@@ -1216,6 +1225,16 @@ bool is_pinned(const void *p) {
 }
 }  // namespace
 
+// How many utterance ranges a host-buffer run is cut into: CTU_HOST_CHUNKS if set (1 = one range), else 8 for batches of
+// at least 16 utterances and 32 MiB of PCM in page-locked buffers.  Modes whose state crosses utterances (the *ss noise seed) stay in one range.
+static int host_chunks(const ctu_engine *e, const ctu_plan *pl, bool pinned) {
+    if (e->ss) return 1;
+    // pageable buffers go through blocking staged copies: cutting those up only adds calls (measured 1.04e8 -> 0.96e8 frames/s)
+    int k = (pinned && pl->n_utt >= 16 && pl->total_samples >= (int64_t)16 << 20) ? 8 : 1;
+    if (const char *v = getenv("CTU_HOST_CHUNKS")) k = std::max(1, atoi(v));
+    return std::min(k, std::max(1, pl->n_utt));
+}
+
 int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
                         int64_t *rows_per_utt) {
     if (!e || !pl_ || pl_->eng != e) return CTU_ERR_INPUT;
@@ -1226,26 +1245,88 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm
     if (pl->total_frames == 0) return CTU_OK;
     try {
         HIP_TRY(hipSetDevice(e->device));
-        // Device buffers are allocated once per plan.  Transfers: a caller buffer from ctu_host_alloc (pinned) is DMA-ed
-        // asynchronously at the link rate; pageable memory goes through the runtime's own staging (hipMemcpy).
-        if (pl->h_pcm.n < (size_t)pl->total_samples) pl->h_pcm.alloc((size_t)pl->total_samples);
-        if (pl->h_rows.n < (size_t)pl->total_frames * d.D) pl->h_rows.alloc((size_t)pl->total_frames * d.D);
-        if (e->do_vad && pl->h_vad.n < (size_t)pl->total_frames) pl->h_vad.alloc((size_t)pl->total_frames);
-        hipStream_t s = nullptr;
-        if (is_pinned(h_pcm)) HIP_TRY(hipMemcpyAsync(pl->h_pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice, s));
-        else HIP_TRY(hipMemcpy(pl->h_pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
-        int rc = ctu_engine_run(e, pl, pl->h_pcm.p, pl->h_rows.p, pl->h_vad.p, s);
-        if (rc != CTU_OK) return rc;
-        if (is_pinned(h_rows)) {
-            HIP_TRY(hipMemcpyAsync(h_rows, pl->h_rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+        // Device buffers are allocated once per plan (per part).  Transfers: a caller buffer from ctu_host_alloc (pinned) is
+        // DMA-ed asynchronously at the link rate; pageable memory goes through the runtime's own staging (hipMemcpy).
+        const bool pin_in = is_pinned(h_pcm), pin_out = is_pinned(h_rows);
+        const int nparts = host_chunks(e, pl, pin_in && pin_out);
+        if (nparts > 1 && (int)pl->parts.size() != nparts) {
+            // ranges of about equal PCM; a part's arena is the slice of the caller's arena that starts PCM_HEAD samples
+            // ahead of its first utterance (the layout rule of ctu_plan_create is translation invariant)
+            pl->parts.clear();
+            pl->part_first.assign(1, 0);
+            const int64_t per = (pl->sample_off[pl->n_utt] - pl->sample_off[0] + nparts - 1) / nparts;
+            for (int k = 1; k < nparts; k++) {
+                int u = pl->part_first.back();
+                const int64_t goal = pl->sample_off[0] + per * k;
+                while (u < pl->n_utt && pl->sample_off[u] < goal) u++;
+                if (u > pl->part_first.back() && u < pl->n_utt) pl->part_first.push_back(u);
+            }
+            pl->part_first.push_back(pl->n_utt);
+            for (size_t k = 0; k + 1 < pl->part_first.size(); k++) {
+                ctu_plan *sub = nullptr;
+                const int u0 = pl->part_first[k], u1 = pl->part_first[k + 1];
+                const int rc = ctu_plan_create(e, pl->nsamples.data() + u0, u1 - u0, &sub);
+                if (rc != CTU_OK) return rc;
+                pl->parts.emplace_back(sub);
+            }
+            for (hipStream_t &st : pl->part_stream)
+                if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        }
+        std::vector<uint8_t> v(e->do_vad ? (size_t)pl->total_frames : 0);
+        if (nparts > 1 && pl->parts.size() > 1) {
+            const int np = (int)pl->parts.size();
+            auto download = [&](int k) {
+                ctu_plan *sp = pl->parts[k].get();
+                if (sp->total_frames == 0) return;
+                hipStream_t st = pl->part_stream[k & 1];
+                float *dst = h_rows + pl->row_off[pl->part_first[k]] * d.D;
+                if (pin_out) HIP_TRY(hipMemcpyAsync(dst, sp->h_rows.p, (size_t)sp->total_frames * d.D * 4, hipMemcpyDeviceToHost, st));
+                else {
+                    HIP_TRY(hipStreamSynchronize(st));
+                    HIP_TRY(hipMemcpy(dst, sp->h_rows.p, (size_t)sp->total_frames * d.D * 4, hipMemcpyDeviceToHost));
+                }
+            };
+            for (int k = 0; k < np; k++) {
+                ctu_plan *sp = pl->parts[k].get();
+                hipStream_t st = pl->part_stream[k & 1];
+                if (sp->total_frames) {
+                    if (sp->h_pcm.n < (size_t)sp->total_samples) sp->h_pcm.alloc((size_t)sp->total_samples);
+                    if (sp->h_rows.n < (size_t)sp->total_frames * d.D) sp->h_rows.alloc((size_t)sp->total_frames * d.D);
+                    if (e->do_vad && sp->h_vad.n < (size_t)sp->total_frames) sp->h_vad.alloc((size_t)sp->total_frames);
+                    const int16_t *src = h_pcm + (pl->sample_off[pl->part_first[k]] - PCM_HEAD);
+                    if (pin_in) HIP_TRY(hipMemcpyAsync(sp->h_pcm.p, src, (size_t)sp->total_samples * 2, hipMemcpyHostToDevice, st));
+                    else HIP_TRY(hipMemcpy(sp->h_pcm.p, src, (size_t)sp->total_samples * 2, hipMemcpyHostToDevice));
+                    const int rc = ctu_engine_run(e, sp, sp->h_pcm.p, sp->h_rows.p, sp->h_vad.p, st);
+                    if (rc != CTU_OK) return rc;
+                }
+                if (k > 0) download(k - 1);  // behind the launch of part k: the copy engines and the kernels overlap
+            }
+            download(np - 1);
+            HIP_TRY(hipStreamSynchronize(pl->part_stream[0]));
+            HIP_TRY(hipStreamSynchronize(pl->part_stream[1]));
+            if (e->do_vad)
+                for (int k = 0; k < np; k++)
+                    if (pl->parts[k]->total_frames)
+                        HIP_TRY(hipMemcpy(v.data() + pl->row_off[pl->part_first[k]], pl->parts[k]->h_vad.p, (size_t)pl->parts[k]->total_frames, hipMemcpyDeviceToHost));
         } else {
-            HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipMemcpy(h_rows, pl->h_rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost));
+            if (pl->h_pcm.n < (size_t)pl->total_samples) pl->h_pcm.alloc((size_t)pl->total_samples);
+            if (pl->h_rows.n < (size_t)pl->total_frames * d.D) pl->h_rows.alloc((size_t)pl->total_frames * d.D);
+            if (e->do_vad && pl->h_vad.n < (size_t)pl->total_frames) pl->h_vad.alloc((size_t)pl->total_frames);
+            hipStream_t s = nullptr;
+            if (pin_in) HIP_TRY(hipMemcpyAsync(pl->h_pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice, s));
+            else HIP_TRY(hipMemcpy(pl->h_pcm.p, h_pcm, (size_t)pl->total_samples * 2, hipMemcpyHostToDevice));
+            int rc = ctu_engine_run(e, pl, pl->h_pcm.p, pl->h_rows.p, pl->h_vad.p, s);
+            if (rc != CTU_OK) return rc;
+            if (pin_out) {
+                HIP_TRY(hipMemcpyAsync(h_rows, pl->h_rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+            } else {
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(h_rows, pl->h_rows.p, (size_t)pl->total_frames * d.D * 4, hipMemcpyDeviceToHost));
+            }
+            if (e->do_vad) HIP_TRY(hipMemcpy(v.data(), pl->h_vad.p, v.size(), hipMemcpyDeviceToHost));
         }
         if (e->do_vad) {
-            std::vector<uint8_t> v((size_t)pl->total_frames);
-            HIP_TRY(hipMemcpy(v.data(), pl->h_vad.p, v.size(), hipMemcpyDeviceToHost));
             if (h_vad) std::memcpy(h_vad, v.data(), v.size());
             if (d.o.vad_apply_mode == "drop") {
                 // rows of non-speech frames are dropped (src/io/batch.cc:237-238): compact each utterance in place

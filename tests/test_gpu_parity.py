@@ -125,6 +125,23 @@ def test_lp_on_uncompressed_bands(Engine):
     _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset plpc -fb_inld off".split(), [sig("CS3")[:30000]])
 
 
+@pytest.mark.parametrize("chunks", ["2", "5"])
+def test_host_runs_in_utterance_ranges(Engine, monkeypatch, chunks):
+    # ctu_engine_run_host cuts large batches into utterance ranges that run on two streams (upload of one range under
+    # the kernels and the download of the previous one); forced here on a small batch: same rows, VAD bytes and drop counts
+    from tests.util import C4
+    utts16 = [synth_utt(300 + i, 9000 + 1777 * i) for i in range(11)]
+    utts8 = [synth_utt(320 + i, 5000 + 1333 * i, fs=8000) for i in range(9)]
+    for cfg, utts in [(C2, utts16), (C2 + ["-fea_delta", "d_a"], utts16), (C4 + ["-vad_apply_mode", "drop"], utts8), (C5, utts16[:4] + [synth_utt(340, 60000)])]:
+        monkeypatch.setenv("CTU_HOST_CHUNKS", "1")
+        one, vone = Engine(cfg).extract(utts, want_vad=True)
+        monkeypatch.setenv("CTU_HOST_CHUNKS", chunks)
+        many, vmany = Engine(cfg).extract(utts, want_vad=True)
+        for a, b, va, vb in zip(one, many, vone, vmany):
+            assert a.shape == b.shape and np.array_equal(a, b)
+            assert np.array_equal(va, vb)
+
+
 def test_exten_16k(Engine):
     cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
     _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
