@@ -43,4 +43,52 @@ __global__ __launch_bounds__(256) void g711_kernel(const uint8_t *__restrict__ c
     }
 }
 
+// -remove_dc1 (src/io/in.cc:343-350): before anything else a frame subtracts the mean of the sample buffer from the
+// buffer itself, so a sample carries the offsets of every frame it has been part of.  With o_t the offset of frame t and
+// m_t the mean of the frame's untouched samples,
+//     o_t = m_t - sum_{j >= 1, j*wshift < window} (window - j*wshift) / window * o_{t-j}          (o_u = 0 for u < 0)
+// and the sample at position i of frame t is read as  x - o_t - sum_{j >= 1, i <= window-1-j*wshift} o_{t-j}  (the front
+// end applies that; the sample ahead of the frame, position -1, without the o_t term).
+// dc1_means: one wave per frame chunk, m_t in double (integer sums: exact).  dc1_offsets: one lane per utterance walks
+// the recurrence in double and stores the offsets as floats.
+__global__ __launch_bounds__(256) void dc1_means_kernel(const int16_t *__restrict__ pcm, const int4 *__restrict__ utt_info,
+                                                        const long long *__restrict__ sample_off, double *__restrict__ mean, int n_utt,
+                                                        int window, int wshift) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blockIdx.y;
+    const int4 ui = utt_info[u];
+    const int64_t r0 = ((int64_t)ui.y << 32) | (uint32_t)ui.x;
+    const int T = ui.z;
+    const int16_t *x = pcm + sample_off[u];
+    for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
+        int sum = 0;  // |sum| <= 32768 * window: fits for windows up to 65535 samples
+        for (int i = lane; i < window; i += 64) sum += x[(int64_t)t * wshift + i];
+        for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) mean[r0 + t] = (double)sum / (double)window;
+    }
+}
+
+__global__ __launch_bounds__(64) void dc1_offsets_kernel(const double *__restrict__ mean, const int4 *__restrict__ utt_info, float *__restrict__ off,
+                                                         int n_utt, int window, int wshift) {
+    const int u = blockIdx.x * 64 + threadIdx.x;
+    if (u >= n_utt) return;
+    const int4 ui = utt_info[u];
+    const int64_t r0 = ((int64_t)ui.y << 32) | (uint32_t)ui.x;
+    const int T = ui.z;
+    constexpr int JM = 8;  // the engine refuses window / wshift > 8
+    double hist[JM] = {0, 0, 0, 0, 0, 0, 0, 0};  // o_{t-1} .. o_{t-8}
+    double cj[JM];
+#pragma unroll
+    for (int j = 1; j <= JM; j++) cj[j - 1] = (j * wshift < window) ? (double)(window - j * wshift) / (double)window : 0.0;
+    for (int t = 0; t < T; t++) {
+        double o = mean[r0 + t];
+#pragma unroll
+        for (int j = 0; j < JM; j++) o -= cj[j] * hist[j];
+#pragma unroll
+        for (int j = JM - 1; j > 0; j--) hist[j] = hist[j - 1];
+        hist[0] = o;
+        off[r0 + t] = (float)o;
+    }
+}
+
 }  // namespace

@@ -140,6 +140,9 @@ struct ctu_plan {
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
     DevBuf<int64_t> d_row_off;
+    DevBuf<double> dc1m;       // -remove_dc1: frame means, then
+    DevBuf<float> dc1;         // the offsets the frames subtract (decode_kernels.h)
+    int max_frames = 0;        // longest utterance of the plan
     // scratch between the kernels of one run; owned by the plan, so plans can run concurrently on different streams
     DevBuf<float> logmel;      // TRAP: log-mel rows [total_frames][B]
     DevBuf<float> base_rows;   // front-end rows ahead of the delta / stacking / CMS passes [total_frames][Dbase]
@@ -165,7 +168,10 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (o.format_in == "htk") return "HTK feature input with signal output";
         if (o.fea_kind == "td-iir-mfcc") return "fea_kind outside the spectral path";
         if (o.dither != 0.) return "-dither != 0 makes outputs depend on file order (src/io/in.cc:205,454)";
-        if (o.remove_dc1) return "-remove_dc1 mutates the sample history across frames (src/io/in.cc:343-350)";
+        if (o.remove_dc1) {
+            if (d.window / d.wshift > 8) return "-remove_dc1 with more than 8 frames over a sample (window / shift above 8)";
+            if (o.fea_E && o.fea_rawenergy) return "-remove_dc1 together with -fea_rawenergy";
+        }
         if (o.nr_mode != "none" && o.nr_mode != "exten") return "nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221)";
         if (o.rasta) return "-nr_rasta";
         if (o.do_vad()) return "VAD together with signal output";
@@ -178,7 +184,10 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.format_in == "htk") return "HTK feature input (-format_in htk) bypasses the spectral path";
     if (o.fea_kind == "td-iir-mfcc" || o.fea_kind == "none") return "fea_kind outside the spectral feature path";
     if (o.dither != 0.) return "-dither != 0 makes outputs depend on file order (src/io/in.cc:205,454)";
-    if (o.remove_dc1) return "-remove_dc1 mutates the sample history across frames (src/io/in.cc:343-350)";
+    if (o.remove_dc1) {
+        if (d.window / d.wshift > 8) return "-remove_dc1 with more than 8 frames over a sample (window / shift above 8)";
+        if (o.fea_E && o.fea_rawenergy) return "-remove_dc1 together with -fea_rawenergy";
+    }
     if (o.nr_mode != "none" && o.nr_mode != "exten") {
         if (o.vadmode == "file") return "-vad file=...: one byte stream for all files, every byte but NUL counts as speech (src/nr/nr.cc:297-301)";
         if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (8 kHz, 25 ms window, -vad burg, 12 cepstral coefficients, plain chain)";
@@ -263,7 +272,7 @@ struct Phase2Tables {
 // the plain cepstral chain: what the specialised instantiations (GEN_PLAIN / GEN_EXTEN with MD) cover
 bool plain_cepstral(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
-    return !o.nr_when_afterFB && d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !d.signal_out;
+    return !o.nr_when_afterFB && d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !d.signal_out;
 }
 // Burg-cepstral VAD criterion fused into the front end (vad_fused.h): 256-point mode, 200-sample window, 14 coefficients (the preset's detector)
 bool vf_eligible(const ctu::Design &d) {
@@ -279,7 +288,7 @@ bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
     return CTU_MD && ss_mode_of(o) && o.vadmode == "burg" && !o.nr_when_afterFB && d.wfft == 256 && d.window == VF_WINDOW &&
-           o.fea_ncepcoefs == SS_NC && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.fb_inld && !o.do_vad() && !d.signal_out &&
+           o.fea_ncepcoefs == SS_NC && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !o.do_vad() && !d.signal_out &&
            !o.rasta && d.post_order == 0 && !d.cms && !o.stat_cmvn && !o.apply_cmvn;
 }
 
@@ -605,7 +614,7 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     // with the VAD export, reads its flags at run time.
     const bool vx = kp.vad_export != 0;
     const int feat = e->feat;
-    const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.dbg && !kp.skip_phase2 && !kp.nr_after_fb;
+    const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.remove_dc1 && !kp.dbg && !kp.skip_phase2 && !kp.nr_after_fb;
     const bool narrow = kp.CW == 16;
     if (e->sy && kp.skip_phase2) {
         launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, false, true>, grid, s, kp);
@@ -938,6 +947,14 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             for (int i = 0; i < n_utt; i++) pl->out_samples[i] = pl->frames[i] * d.wshift + (d.window - d.wshift);
             pl->ybuf.alloc((size_t)ro * d.window);
         }
+        for (int i = 0; i < n_utt; i++) pl->max_frames = std::max<int>(pl->max_frames, (int)pl->frames[i]);
+        if (d.o.remove_dc1) {
+            pl->utt_info.upload(uinfo);
+            std::vector<long long> so64(pl->sample_off.begin(), pl->sample_off.end());
+            pl->d_sample_off.upload(so64);
+            pl->dc1m.alloc((size_t)std::max<int64_t>(ro, 1));
+            pl->dc1.alloc((size_t)std::max<int64_t>(ro, 1));
+        }
         if (d.kind == ctu::FeaKind::TrapDct || d.post_order > 0 || d.cms || d.o.stat_cmvn || d.o.apply_cmvn) {
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
@@ -1035,6 +1052,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.inv_window = 1.0f / (float)d.window;
         kp.inv_window_d = 1.0 / (double)d.window;
         kp.remove_dc = d.o.remove_dc;
+        kp.remove_dc1 = d.o.remove_dc1 ? 1 : 0;
+        kp.dc1_J = d.window / d.wshift;
+        kp.dc1 = pl->dc1.p;
         kp.fb_power = d.o.fb_power;
         kp.fb_inld = d.o.fb_inld;
         kp.lifter_on = d.o.fea_lifter > 1;
@@ -1054,6 +1074,11 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         HIP_TRY(hipMemsetAsync(e->stamps.p, 0, e->stamps.n * 8, s));
         kp.stamps = e->stamps.p;
 #endif
+        if (d.o.remove_dc1) {
+            const int gx = std::max(1, std::min((pl->max_frames + 3) / 4, 64));
+            hipLaunchKernelGGL(dc1_means_kernel, dim3(gx, pl->n_utt), dim3(256), 0, s, d_pcm, pl->utt_info.p, pl->d_sample_off.p, pl->dc1m.p, pl->n_utt, d.window, d.wshift);
+            hipLaunchKernelGGL(dc1_offsets_kernel, dim3((pl->n_utt + 63) / 64), dim3(64), 0, s, pl->dc1m.p, pl->utt_info.p, pl->dc1.p, pl->n_utt, d.window, d.wshift);
+        }
         HIP_TRY(hipEventRecord(e->ev0, s));
         auto launch = [&] {
             switch (e->nz) {

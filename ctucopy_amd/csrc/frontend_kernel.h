@@ -71,6 +71,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
     const bool o_skip_phase2 = SY ? true : (FULL ? p.skip_phase2 != 0 : false);
+    const bool o_dc1 = FULL ? p.remove_dc1 != 0 : false;  // -remove_dc1 (decode_kernels.h): run-time flags only
     const bool per_wave = (GEN == GEN_EXTEN || FULL || VF || SS) ? p.per_wave != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]
@@ -120,6 +121,19 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         navg[j] = (xstate_t)0.95;
         yavg[j] = (xstate_t)0.05;
     }
+
+    // -remove_dc1: ov[0] = o_t, ov[j] = o_{t-j} of one frame; what position i of the frame has had subtracted so far
+    constexpr int DCJ = 8;
+    auto dc1_load = [&](float (&ov)[DCJ + 1], int64_t frame_row, int t) {
+#pragma unroll
+        for (int j = 0; j <= DCJ; j++) ov[j] = (j <= p.dc1_J && t - j >= 0) ? p.dc1[frame_row - j] : 0.f;
+    };
+    auto dc1_cum = [&](const float (&ov)[DCJ + 1], int i, bool with_own) {
+        float c = with_own ? ov[0] : 0.f;
+#pragma unroll
+        for (int j = 1; j <= DCJ; j++) c += (j <= p.dc1_J && i <= p.window - 1 - j * p.wshift) ? ov[j] : 0.f;
+        return c;
+    };
 
     VadRun vrun;  // VF: the VAD's recurrences along the wave's utterance
     if constexpr (VF) vad_run_reset(vrun);
@@ -269,12 +283,24 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     const int16_t *xb = p.pcm + rec.sbase + (int64_t)cb_ * p.wshift + l16;
                     const bool start_a = (l16 == 0) && (rec.t0 + ca == 0), start_b = (l16 == 0) && (rec.t0 + cb_ == 0);
                     float dca = 0.f, dcb = 0.f;
+                    float ova[DCJ + 1], ovb[DCJ + 1];
+                    if (o_dc1) {
+                        dc1_load(ova, rbase + ca, rec.t0 + ca);
+                        dc1_load(ovb, rbase + cb_, rec.t0 + cb_);
+                    }
     #pragma unroll
                     for (int j = 0; j < NZ; j++) {
                         const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];
                         const float w = (j & 1) ? w4.z : w4.x;  // 0 beyond the window
                         float pa = (float)xa[16 * j - 1], pb = (float)xb[16 * j - 1];
-                        const float a0 = (float)xa[16 * j], b0 = (float)xb[16 * j];
+                        float a0 = (float)xa[16 * j], b0 = (float)xb[16 * j];
+                        if (o_dc1) {
+                            const int i = 16 * j + l16;
+                            pa -= dc1_cum(ova, i - 1, i >= 1);
+                            pb -= dc1_cum(ovb, i - 1, i >= 1);
+                            a0 -= dc1_cum(ova, i, true);
+                            b0 -= dc1_cum(ovb, i, true);
+                        }
                         if (j == 0) {
                             pa = start_a ? 0.f : pa;
                             pb = start_b ? 0.f : pb;
@@ -299,6 +325,8 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     }
                 } else {
                     float dc = 0.f;
+                    float ov0[DCJ + 1];
+                    if (o_dc1) dc1_load(ov0, rbase + fc, rec.t0 + fc);
                     pcm4 q[NZ];
                     // samples x[i0-2 .. i0+1] of row j of this lane's frame: i0 = 32 j + 2 l16
                     const int16_t *x = p.pcm + rec.sbase + (int64_t)fc * p.wshift + 2 * l16 - 2;
@@ -309,8 +337,14 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                         const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
                         const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
                         float xm = (float)(int16_t)(q[j].lo >> 16);
-                        const float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
-                        const float x1 = (float)(int16_t)(q[j].hi >> 16);
+                        float x0 = (float)(int16_t)(q[j].hi & 0xffffu);
+                        float x1 = (float)(int16_t)(q[j].hi >> 16);
+                        if (o_dc1) {
+                            const int i = 32 * j + 2 * l16;
+                            xm -= dc1_cum(ov0, i - 1, i >= 1);
+                            x0 -= dc1_cum(ov0, i, true);
+                            x1 -= dc1_cum(ov0, i + 1, true);
+                        }
                         if (j == 0) xm = file_start ? 0.f : xm;  // first sample of the file: history is 0
                         const float y0 = w0 * (x0 - p.preem * xm);
                         const float y1 = w1 * (x1 - p.preem * x0);  // w is 0 beyond the window

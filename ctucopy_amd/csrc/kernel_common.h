@@ -63,6 +63,8 @@ struct KParams {
     int lift_off;
     float preem, inv_window;
     int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
+    int remove_dc1, dc1_J;      // -remove_dc1: offsets of the frames (dc1, one per frame) and floor(window / wshift) <= 8
+    const float *dc1;
     float nr_p, nr_a;
     unsigned long long *stamps;  // [grid][NWAVE][16] (CTU_STAMP builds)
     int skip_phase2;  // signal output (row N3): spectra are exported, nothing is projected

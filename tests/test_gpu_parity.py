@@ -142,6 +142,20 @@ def test_host_runs_in_utterance_ranges(Engine, monkeypatch, chunks):
             assert np.array_equal(va, vb)
 
 
+def test_remove_dc1(Engine):
+    # -remove_dc1 (src/io/in.cc:343-350): every frame subtracts the buffer mean from the buffer itself; the offsets follow
+    # a recurrence over the frames (decode_kernels.h), the front end subtracts what each sample has accumulated
+    dc = [(synth_utt(60 + i, 9000 + 3111 * i).astype(np.int32) + 700 * (1 - 2 * (i & 1))).clip(-32768, 32767).astype(np.int16) for i in range(4)]
+    _check(Engine, C2 + ["-remove_dc1", "on"], dc + [sig("CS0")[:30000]])
+    _check(Engine, C2 + ["-remove_dc1", "on", "-remove_dc", "off"], dc[:2])
+    _check(Engine, C2 + ["-remove_dc1", "on", "-w", "25", "-s", "5"], dc[:2])      # five frames over a sample
+    _check(Engine, C2 + ["-remove_dc1", "on", "-w", "32", "-s", "16"], dc[:2])     # the shift divides the window
+    _check(Engine, C3 + ["-remove_dc1", "on"], dc[:2])
+    dc8 = [(synth_utt(70 + i, 7000 + 2111 * i, fs=8000).astype(np.int32) - 500).clip(-32768, 32767).astype(np.int16) for i in range(3)]
+    _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -remove_dc1 on".split(), dc8 + [sig("CS3")[:30000]])
+    _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0 -remove_dc1 on -w 30 -s 10".split(), dc8[:2], tol=1e-3)
+
+
 def test_exten_16k(Engine):
     cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
     _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
