@@ -84,6 +84,7 @@ struct ctu_engine {
     std::unique_ptr<ctu::Design> design;
     int device = 0;
     int n_cu = 256;
+    int kstride = 1;            // > 1: an FFT size below 256 carried by the 256-point mode (ctu_engine_create)
     std::string err;
     int feat = FEAT_DCTC;
     int nz = 16;
@@ -234,6 +235,7 @@ std::string unsupported_reason(const ctu::Design &d) {
             if (nc > 32 || nc < 2) return "more than 32 (or fewer than 2) VAD cepstral coefficients";
         }
         if (o.vad_filter_order > 31) return "VAD filter order above 31";
+        if (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" && d.window <= 128) return "Burg-cepstral VAD with an FFT size below 256 (the detector's inverse transform has the reference's size)";
     }
     if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
     if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
@@ -727,6 +729,23 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
     try {
         ctu::Opts o = ctu::Opts::from_args(to_args(argc, argv));
         e->design.reset(new ctu::Design(o));
+        // FFT sizes below 256 (windows up to 128 samples): the N-point spectrum of a frame is every (256/N)-th bin of its
+        // 256-point spectrum, because the frame is zero beyond the window either way.  The engine runs the 256-point mode
+        // with the filter bank spread onto those bins (zero weight in between); sums over bins step by kstride.
+        ctu::Design &d = *e->design;
+        if (d.wfft < 256 && d.wfft >= 32 && !d.signal_out) {
+            const int S = 256 / d.wfft;
+            e->kstride = S;
+            for (auto &row : d.fb) {
+                std::vector<double> wide(129, 0.0);
+                for (int k = 0; k < d.K; k++) wide[(size_t)k * S] = row[k];
+                row.swap(wide);
+            }
+            for (int &f : d.fb_first) f *= S;
+            for (int &l : d.fb_last) l *= S;
+            d.K = 129;
+            d.wfft = 256;
+        }
     } catch (const std::exception &ex) {
         g_create_error = ex.what();
         return CTU_ERR_OPTS;
@@ -1052,6 +1071,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.inv_window = 1.0f / (float)d.window;
         kp.inv_window_d = 1.0 / (double)d.window;
         kp.remove_dc = d.o.remove_dc;
+        kp.kstride = e->kstride;
         kp.remove_dc1 = d.o.remove_dc1 ? 1 : 0;
         kp.dc1_J = d.window / d.wshift;
         kp.dc1 = pl->dc1.p;

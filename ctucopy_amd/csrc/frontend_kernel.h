@@ -761,7 +761,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             } else {
                 const int f8e = lane >> 3, ge = lane & 7;
                 float es = 0.f;
-                for (int k = ge; k < p.K; k += 8) {
+                for (int k = ge * p.kstride; k < p.K; k += 8 * p.kstride) {
                     const float x = Pw[f8e * PSTRIDE + k];
                     es += x * x;
                 }
@@ -800,13 +800,13 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             if (o_e_mode == 5) {  // -nr_when afterFB: E = in->E = log(2 (P0/2 + sum P_i + P_{K-1}/2)) of the power spectrum (src/io/in.cc:404-413, batch.cc:101-104)
-                for (int k = g; k < p.K; k += 8) {
+                for (int k = g * p.kstride; k < p.K; k += 8 * p.kstride) {
                     const float x = prow2[k];
                     esum += ((k == 0 || k == p.K - 1) ? 0.5 : 1.0) * (o_fb_power ? (double)x : (double)x * x);
                 }
             }
             if (o_e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) on the post-NR vector (src/nr/nr.cc:36-45)
-                for (int k = g; k < p.K; k += 8) {
+                for (int k = g * p.kstride; k < p.K; k += 8 * p.kstride) {
                     const float x = prow2[k];
                     esum += ((k == 0 || k == p.K - 1) ? 0.5 : 1.0) * ((double)x * x);
                 }

@@ -63,6 +63,7 @@ struct KParams {
     int lift_off;
     float preem, inv_window;
     int remove_dc, fb_power, fb_inld, lifter_on, nr_exten;
+    int kstride;                // FFT sizes below 256 run as the 256-point mode: their bin k is bin k * kstride of it
     int remove_dc1, dc1_J;      // -remove_dc1: offsets of the frames (dc1, one per frame) and floor(window / wshift) <= 8
     const float *dc1;
     float nr_p, nr_a;

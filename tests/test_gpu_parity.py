@@ -156,6 +156,23 @@ def test_remove_dc1(Engine):
     _check(Engine, "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0 -remove_dc1 on -w 30 -s 10".split(), dc8[:2], tol=1e-3)
 
 
+def test_fft_sizes_below_256(Engine):
+    # windows of 128 samples or fewer: src/io/opts.cc:277-280 picks a 128-, 64- or 32-point FFT; the engine carries them on
+    # the 256-point mode (their bins are every 2nd / 4th / 8th bin of it)
+    m8 = "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97".split()
+    u8 = [synth_utt(90 + i, 5000 + 1777 * i, fs=8000) for i in range(3)] + [sig("CS3")[:20000]]
+    _check(Engine, m8 + ["-w", "16", "-s", "8"], u8)                       # 128 samples -> 128 points
+    _check(Engine, m8 + ["-w", "10", "-s", "5", "-fea_E", "on"], u8)       # 80 samples -> 128 points, energy over the bins
+    _check(Engine, m8 + ["-w", "8", "-s", "4", "-fb_definition", "1-10/10filters", "-fea_ncepcoefs", "8"], u8[:2])   # 64 points
+    _check(Engine, C2 + ["-w", "8", "-s", "4", "-fea_kind", "logspec"], [synth_utt(95, 20000)])   # 16 kHz, 128 samples
+    cfg = m8 + ["-w", "16", "-s", "8", "-nr_mode", "exten", "-fea_E", "on"]
+    eng = Engine(cfg)
+    orc = Oracle(cfg)
+    for u, g in zip(u8[:2], eng.extract(u8[:2])):
+        _assert_rows(g, orc.process(u), cfg)
+    _vad_agreement(Engine, m8 + "-w 16 -s 8 -vad_out_mode vad -vad_cri_mode energy".split(), u8, 1.0)
+
+
 def test_exten_16k(Engine):
     cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
     _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
