@@ -1,0 +1,204 @@
+// FFT sizes of 1024 to 4096 points (windows of 513 to 4096 samples: 22.05 / 32 / 44.1 / 48 kHz input, or long windows;
+// src/io/opts.cc:277-280 allows any power of two).  The 16-lane register transforms of frontend_kernel.h are built for 512
+// and 256 points and for P rows of 260 floats; these sizes take the plain road: one workgroup per frame, the packed real
+// FFT as a Stockham radix-2 autosort through two LDS buffers, the power spectrum in LDS, four lanes per band for the
+// filter bank, one lane per output coefficient.  The plain chain only (no noise reduction, no VAD): pre-emphasis,
+// window, mean removal, |.|^2 or |.|, any filter bank, ^0.33, log, DCT / band outputs / LP analysis, the energy column.
+// Included by engine.hip.
+#pragma once
+
+namespace {
+
+struct BigParams {
+    const int16_t *pcm;
+    float *rows, *logmel;
+    const TileRec *tiles;
+    int n_tiles;
+    const float *win;        // [window] Hamming
+    const float2 *tw;        // [wfft/2] W_wfft^m = (cos, -sin)(2 pi m / wfft)
+    const float *fbw;        // [B][K] dense filter bank
+    const int *fb_range;     // [B][2] first / last non-zero bin
+    const float *coef;       // dctc: [ncoef_out][B] rows in writer order (norm and lifter folded in); lp: [lporder+1][B] as doubles below
+    const double *coef_d;    // lp: cosine iDFT rows in double [lporder+1][B]
+    const float *lifter;     // [ncep]
+    const int *row_slot;     // lp: output slot of cepstrum n (or -1)
+    int wfft, K, window, wshift, B, D, ncoef_out, feat, e_mode, e_slot;
+    int remove_dc, fb_power, fb_inld, band_log, band_to_scratch, lp_is_lpa, lporder, ncep, lifter_on;
+    float preem;
+};
+
+__device__ __forceinline__ double block_sum(double v, double *red) {  // 256 threads; red: 4 doubles of LDS
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const int N = p.wfft, Nc = N >> 1, K = p.K;
+    float2 *A = reinterpret_cast<float2 *>(smem);      // [Nc]
+    float2 *Bf = A + Nc;                               // [Nc]
+    float *P = reinterpret_cast<float *>(Bf + Nc);     // [K] (+3 padding)
+    float *Y = P + ((K + 3) & ~3);                     // [64] band values
+    double *red = reinterpret_cast<double *>(Y + 64);  // [4]
+    const int tid = threadIdx.x;
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const TileRec rec = load_rec(p.tiles, tile);
+        for (int f = 0; f < rec.nvalid; f++) {
+            const int16_t *x = p.pcm + rec.sbase + (int64_t)f * p.wshift;
+            const bool file_start = rec.t0 + f == 0;
+            // ---- pre-emphasis x window (src/io/in.cc:364-372), packed as z[n] = y[2n] + i y[2n+1]
+            float *yb = reinterpret_cast<float *>(A);
+            double part = 0.0, raw = 0.0;
+            for (int i = tid; i < N; i += 256) {
+                float y = 0.f;
+                if (i < p.window) {
+                    const float xi = (float)x[i];
+                    const float xm = (i == 0 && file_start) ? 0.f : (float)x[i - 1];
+                    y = p.win[i] * (xi - p.preem * xm);
+                    part += (double)y;
+                    if (i >= 1) raw += (double)xi * (double)xi;
+                }
+                yb[i] = y;
+            }
+            if (p.remove_dc) {  // src/io/in.cc:375-382
+                const float m = (float)(block_sum(part, red) / (double)p.window);
+                for (int i = tid; i < p.window; i += 256) yb[i] -= m;
+            }
+            double e_raw = 0.0;
+            if (p.e_mode == 4) e_raw = block_sum(raw, red);
+            __syncthreads();
+            // ---- Nc-point complex FFT, Stockham radix-2: log2(Nc) passes between the two buffers
+            float2 *src = A, *dst = Bf;
+            for (int Ns = 1; Ns < Nc; Ns <<= 1) {
+                const int tstep = Nc / Ns;  // W_{2Ns}^k = W_wfft^(k * Nc / Ns)
+                for (int j = tid; j < (Nc >> 1); j += 256) {
+                    const int k = j & (Ns - 1);
+                    const float2 w = p.tw[k * tstep];
+                    const float2 a = src[j], b0 = src[j + (Nc >> 1)];
+                    const float2 b = make_float2(b0.x * w.x - b0.y * w.y, b0.x * w.y + b0.y * w.x);
+                    const int j0 = ((j - k) << 1) + k;
+                    dst[j0] = make_float2(a.x + b.x, a.y + b.y);
+                    dst[j0 + Ns] = make_float2(a.x - b.x, a.y - b.y);
+                }
+                __syncthreads();
+                float2 *t_ = src;
+                src = dst;
+                dst = t_;
+            }
+            // ---- untangle the packed transform, |.|^2 (src/io/in.cc:388-394), bins 0..Nc
+            for (int k = tid; k <= Nc; k += 256) {
+                float pw;
+                if (k == 0) {
+                    const float v = src[0].x + src[0].y;
+                    pw = p.remove_dc ? 1e-10f : v * v;
+                } else if (k == Nc) {
+                    const float v = src[0].x - src[0].y;
+                    pw = v * v;
+                } else {
+                    const float2 a = src[k], c = src[Nc - k], w = p.tw[k];
+                    const float sr = a.x + c.x, si = a.y - c.y, dr = a.x - c.x, di = a.y + c.y;
+                    // X = (s - i W d) / 2 with W = (w.x, w.y): -i W d = (w.x di + w.y dr, w.y di - w.x dr) ... conj convention of tw = (cos, -sin)
+                    const float tr = w.x * di + w.y * dr, ti = w.y * di - w.x * dr;
+                    const float ur = sr + tr, ui = si + ti;
+                    pw = 0.25f * (ur * ur + ui * ui);
+                }
+                P[k] = p.fb_power ? pw : sqrtf(pw);  // src/io/in.cc:415-417
+            }
+            __syncthreads();
+            double e_spec = 0.0;
+            if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) (src/nr/nr.cc:36-45)
+                double s = 0.0;
+                for (int k = tid; k < K; k += 256) s += ((k == 0 || k == K - 1) ? 0.5 : 1.0) * (double)P[k] * (double)P[k];
+                e_spec = block_sum(s, red);
+            }
+            // ---- filter bank: lanes 4b..4b+3 share band b (src/fea/fb.cc:60-83)
+            {
+                const int b = tid >> 2, q = tid & 3;
+                float acc = 0.f;
+                if (b < p.B) {
+                    const int k0 = p.fb_range[2 * b], k1 = p.fb_range[2 * b + 1];
+                    const float *w = p.fbw + (size_t)b * K;
+                    for (int k = k0 + q; k <= k1; k += 4) acc += w[k] * P[k];
+                }
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (p.fb_inld) acc = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(acc));
+                if (q == 0 && b < 64) Y[b] = b < p.B ? acc : 0.f;
+            }
+            __syncthreads();
+            const int64_t row = rec.rbase + f;
+            double e_band = 0.0;
+            if (p.e_mode == 3 && tid == 0) {  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
+                for (int b = 0; b < p.B; b++) e_band += ((b == 0 || b == p.B - 1) ? 0.5 : 1.0) * (double)Y[b] * (double)Y[b];
+            }
+            if (p.feat == FEAT_BANDS) {
+                float *dst_ = p.band_to_scratch ? p.logmel : p.rows;
+                const int out_w = p.band_to_scratch ? p.B : p.D;
+                if (tid < p.B) dst_[row * out_w + tid] = p.band_log ? __builtin_amdgcn_logf(Y[tid]) * 0.69314718056f : Y[tid];
+            } else if (p.feat == FEAT_DCTC) {
+                if (tid < p.ncoef_out && p.row_slot[tid] >= 0) {
+                    const float *c = p.coef + (size_t)tid * p.B;
+                    float acc = 0.f;
+                    for (int b = 0; b < p.B; b++) acc += c[b] * (__builtin_amdgcn_logf(Y[b]) * 0.69314718056f);
+                    p.rows[row * p.D + tid] = acc;
+                }
+            } else if (tid == 0) {
+                // LP analysis in double by one lane (src/fea/fea_impl.cc:163-222, 251-284): R by cosine iDFT, Levinson-Durbin, a -> c
+                double R[MAX_LP + 1], a[MAX_LP + 1], aa[MAX_LP + 1], cc[MAX_LP + 1];
+                const int P_ = p.lporder;
+                for (int k = 0; k <= P_; k++) {
+                    double r = 0.0;
+                    for (int b = 0; b < p.B; b++) {
+                        const double y = p.fb_inld ? (double)Y[b] : (double)Y[b] * (double)Y[b];
+                        r += p.coef_d[(size_t)k * p.B + b] * y;
+                    }
+                    R[k] = r;
+                }
+                float *orow = p.rows + row * p.D;
+                if (p.e_mode == 2) orow[p.e_slot] = (float)log(R[0]);
+                double rc = -R[1] / R[0], err = R[0] * (1 - rc * rc);
+                a[0] = aa[0] = 1;
+                a[1] = aa[1] = rc;
+                for (int ik = 2; ik <= P_; ik++) {
+                    double dm = R[ik];
+                    for (int n = 1; n < ik; n++) dm += aa[n] * R[ik - n];
+                    rc = -dm / err;
+                    a[ik] = rc;
+                    for (int n = 1; n < ik; n++) a[n] = aa[n] + rc * aa[ik - n];
+                    for (int n = 1; n <= ik; n++) aa[n] = a[n];
+                    err *= (1 - rc * rc);
+                }
+                if (p.lp_is_lpa) {
+                    for (int i = 1; i <= P_; i++) orow[i - 1] = (float)a[i];
+                } else {
+                    cc[0] = log(err);
+                    for (int n = 1; n <= p.ncep; n++) {
+                        double sum = 0;
+                        for (int k = 1; k < n; k++)
+                            if (k <= P_) sum += (double)(n - k) * cc[n - k] * a[k];
+                        cc[n] = (n <= P_ ? -a[n] : 0.0) - sum / (double)n;
+                    }
+                    for (int n = 0; n <= p.ncep; n++) {
+                        double val = cc[n];
+                        if (n >= 1 && p.lifter_on) val *= (double)p.lifter[n - 1];
+                        const int slot = p.row_slot[n];
+                        if (slot >= 0) orow[slot] = (float)val;
+                    }
+                }
+            }
+            if (p.e_mode && p.e_mode != 2 && tid == 0 && !(p.feat == FEAT_BANDS && p.band_to_scratch)) {
+                double e = 0.0;
+                if (p.e_mode == 1) e = log(2.0 * e_spec);
+                else if (p.e_mode == 3) e = log(2.0 * e_band);
+                else if (p.e_mode == 4) e = log(e_raw);
+                p.rows[row * p.D + p.e_slot] = (float)e;
+            }
+            __syncthreads();  // P, Y and the FFT buffers are rewritten by the next frame
+        }
+    }
+}
+
+}  // namespace

@@ -37,6 +37,7 @@
 #include "frontend_kernel.h"
 #include "trap_kernel.h"
 #include "decode_kernels.h"
+#include "bigfft_kernel.h"
 
 namespace {
 
@@ -91,6 +92,12 @@ struct ctu_engine {
     int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
     DevBuf<float> lanec, ftab, trapG;
     DevBuf<int> itab;
+    // FFT sizes of 1024 to 4096 points (bigfft_kernel.h)
+    bool big = false;
+    DevBuf<float> big_win, big_fbw, big_coef, big_lifter;
+    DevBuf<float2> big_tw;
+    DevBuf<int> big_range, big_slot;
+    DevBuf<double> big_coef_d;
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, cfd_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
     bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
@@ -237,7 +244,14 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (o.vad_filter_order > 31) return "VAD filter order above 31";
         if (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" && d.window <= 128) return "Burg-cepstral VAD with an FFT size below 256 (the detector's inverse transform has the reference's size)";
     }
-    if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
+    if (d.wfft >= 1024) {  // bigfft_kernel.h: the plain chain
+        if (d.wfft > 4096) return "FFT size above 4096";
+        if (o.nr_mode != "none" || o.nr_when_afterFB) return "noise reduction with an FFT size above 512";
+        if (o.do_vad()) return "VAD with an FFT size above 512";
+        if (o.remove_dc1) return "-remove_dc1 with an FFT size above 512";
+        if (d.B > 64) return "more than 64 bands with an FFT size above 512";
+    }
+    else if (d.wfft != 512 && d.wfft != 256) return "FFT size below 32";
     if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
@@ -506,9 +520,85 @@ double check_phase2(const ctu::Design &d, const Phase2Tables &t) {
     return worst;
 }
 
+void build_big_tables(ctu_engine *e) {
+    const ctu::Design &d = *e->design;
+    const double pi = 3.14159265358979323846;
+    std::vector<float> win(d.hamming.begin(), d.hamming.end());
+    e->big_win.upload(win);
+    std::vector<float2> tw((size_t)d.wfft / 2);
+    for (int m = 0; m < d.wfft / 2; m++) {
+        const double a = 2.0 * pi * (double)m / (double)d.wfft;
+        tw[m] = make_float2((float)std::cos(a), (float)-std::sin(a));
+    }
+    e->big_tw.upload(tw);
+    std::vector<float> fbw((size_t)d.B * d.K, 0.f);
+    std::vector<int> range((size_t)d.B * 2);
+    for (int b = 0; b < d.B; b++) {
+        for (int k = d.fb_first[b]; k <= d.fb_last[b]; k++) fbw[(size_t)b * d.K + k] = (float)d.fb[b][k];
+        range[2 * b] = d.fb_first[b];
+        range[2 * b + 1] = d.fb_last[b];
+    }
+    e->big_fbw.upload(fbw);
+    e->big_range.upload(range);
+    e->ncoef_out = 0;
+    std::vector<float> coef(4, 0.f);
+    std::vector<double> coef_d(4, 0.0);
+    std::vector<int> slot(4, -1);
+    if (d.kind == ctu::FeaKind::Dctc) {
+        // row r of the table is the value written to output slot r (c1..cN, then c0): norm and lifter are in d.dct
+        std::vector<int> coef_of_slot(d.nfea, -1);
+        int nout = 0;
+        for (int i = 0; i < d.nfea; i++)
+            if (d.row_slot[i] >= 0) {
+                coef_of_slot[d.row_slot[i]] = i;
+                nout = std::max(nout, d.row_slot[i] + 1);
+            }
+        e->ncoef_out = nout;
+        coef.assign((size_t)std::max(nout, 1) * d.B, 0.f);
+        slot.assign(std::max(nout, 1), -1);
+        for (int r = 0; r < nout; r++) {
+            slot[r] = coef_of_slot[r];
+            if (coef_of_slot[r] >= 0)
+                for (int b = 0; b < d.B; b++) coef[(size_t)r * d.B + b] = (float)d.dct[(size_t)coef_of_slot[r] * d.B + b];
+        }
+    } else if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
+        coef_d.assign(d.idft.begin(), d.idft.end());
+        slot.assign(d.row_slot.begin(), d.row_slot.end());
+        while (slot.size() < (size_t)MAX_LP + 2) slot.push_back(-1);
+    }
+    e->big_coef.upload(coef);
+    e->big_coef_d.upload(coef_d);
+    e->big_slot.upload(slot);
+    std::vector<float> lif(d.lifter.begin(), d.lifter.end());
+    lif.push_back(0.f);
+    e->big_lifter.upload(lif);
+    e->lds_bytes = 0;
+    e->mode = 0;
+    e->nz = 16;
+    // the tables of the 512 / 256-point kernels stay empty
+    e->ftab.upload(std::vector<float>(4, 0.f));
+    e->itab.upload(std::vector<int>(4, 0));
+    e->lanec.upload(std::vector<float>(16 * LANEC, 0.f));
+    if (d.kind == ctu::FeaKind::TrapDct) {
+        std::vector<float> g(d.trap.begin(), d.trap.end());
+        e->trapG.upload(g);
+    }
+    switch (d.kind) {
+        case ctu::FeaKind::Dctc: e->feat = FEAT_DCTC; break;
+        case ctu::FeaKind::Lpc:
+        case ctu::FeaKind::Lpa: e->feat = FEAT_LP; break;
+        default: e->feat = FEAT_BANDS; break;
+    }
+}
+
 void build_tables(ctu_engine *e) {
     const ctu::Design &d = *e->design;
     const double pi = 3.14159265358979323846;
+    e->big = d.wfft >= 1024;
+    if (e->big) {
+        build_big_tables(e);
+        return;
+    }
     // ---- per-lane constant records (see LC_* above)
     const bool mode1 = d.wfft == 256;
     e->mode = mode1 ? 1 : 0;
@@ -1106,7 +1196,22 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 default: e->mode ? launch_vx<16, 1>(e, dim3(grid), s, kp) : launch_vx<16, 0>(e, dim3(grid), s, kp); break;
             }
         };
-        if (!e->ss) launch();
+        if (e->big) {
+            BigParams bp;
+            std::memset(&bp, 0, sizeof bp);
+            bp.pcm = d_pcm; bp.rows = kp.rows; bp.logmel = kp.logmel; bp.tiles = pl->tiles.p; bp.n_tiles = pl->n_tiles;
+            bp.win = e->big_win.p; bp.tw = e->big_tw.p; bp.fbw = e->big_fbw.p; bp.fb_range = e->big_range.p;
+            bp.coef = e->big_coef.p; bp.coef_d = e->big_coef_d.p; bp.lifter = e->big_lifter.p; bp.row_slot = e->big_slot.p;
+            bp.wfft = d.wfft; bp.K = d.K; bp.window = d.window; bp.wshift = d.wshift; bp.B = d.B; bp.D = kp.D;
+            bp.ncoef_out = e->ncoef_out; bp.feat = e->feat; bp.e_mode = kp.e_mode; bp.e_slot = kp.e_slot;
+            bp.remove_dc = kp.remove_dc; bp.fb_power = kp.fb_power; bp.fb_inld = kp.fb_inld; bp.band_log = kp.band_log;
+            bp.band_to_scratch = kp.band_to_scratch; bp.lp_is_lpa = kp.lp_is_lpa; bp.lporder = kp.lporder; bp.ncep = kp.ncep;
+            bp.lifter_on = kp.lifter_on; bp.preem = kp.preem;
+            const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8;
+            const int g = std::max(1, std::min(pl->n_tiles, e->n_cu * 8));
+            hipLaunchKernelGGL(bigfft_kernel, dim3(g), dim3(256), shm, s, bp);
+        }
+        else if (!e->ss) launch();
         else {
             // hwss / fwss / 2fwss: a file's noise estimate starts from the vector the previous file of the list left
             // behind (src/nr/nr.cc:212-221), which chains the whole list.  Everything but that seed is independent per

@@ -173,6 +173,21 @@ def test_fft_sizes_below_256(Engine):
     _vad_agreement(Engine, m8 + "-w 16 -s 8 -vad_out_mode vad -vad_cri_mode energy".split(), u8, 1.0)
 
 
+def test_fft_sizes_above_512(Engine):
+    # windows above 512 samples (src/io/opts.cc:277-280: 1024 / 2048 / 4096 points): bigfft_kernel.h, the plain chain
+    u16 = [synth_utt(110 + i, 20000 + 3777 * i) for i in range(3)] + [sig("CS0")[:30000]]
+    _check(Engine, C2 + ["-w", "40", "-s", "10"], u16)                                   # 640 samples -> 1024 points
+    _check(Engine, C2 + ["-w", "40", "-s", "10", "-fea_E", "on", "-fea_delta", "d_a"], u16[:2])
+    _check(Engine, C3 + ["-w", "64", "-s", "16"], u16[:2])                               # PLP on exactly 1024 samples
+    _check(Engine, C3 + ["-w", "50", "-s", "10", "-fb_inld", "off", "-fea_kind", "lpa", "-fea_ncepcoefs", "12"], u16[:2])
+    _check(Engine, C2 + ["-w", "40", "-s", "10", "-fea_kind", "logspec", "-fea_E", "on", "-remove_dc", "off"], u16[:2])
+    m44 = "-fs 44100 -format_in raw -format_out htk -preset mfcc -preem 0.97".split()
+    u44 = [synth_utt(120 + i, 30000 + 5111 * i) for i in range(2)]
+    _check(Engine, m44, u44)                                                            # 1102 samples -> 2048 points
+    _check(Engine, m44 + ["-fea_rawenergy", "on", "-fea_E", "on", "-fb_power", "off"], u44, tol=1e-3)
+    _check(Engine, "-fs 48000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 64 -s 20".split(), u44)   # 3072 -> 4096
+
+
 def test_exten_16k(Engine):
     cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
     _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
