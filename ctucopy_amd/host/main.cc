@@ -21,6 +21,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "g711.h"
@@ -487,10 +488,11 @@ int real_main(int argc, char **argv) {
         // speaker table in order of first appearance (cmvn_POST::add_spk, src/fea/post_impl.cc:120-142)
         std::vector<std::string> spk_names;
         std::vector<int32_t> spk_of(items.size());
+        std::unordered_map<std::string, int32_t> spk_index;
         for (size_t i = 0; i < items.size(); i++) {
-            auto f = std::find(spk_names.begin(), spk_names.end(), items[i].spk);
-            spk_of[i] = (int32_t)(f - spk_names.begin());
-            if (f == spk_names.end()) spk_names.push_back(items[i].spk);
+            auto ins = spk_index.emplace(items[i].spk, (int32_t)spk_names.size());
+            if (ins.second) spk_names.push_back(items[i].spk);
+            spk_of[i] = ins.first->second;
         }
         const int n_spk = (int)spk_names.size(), cols = ctu_cmvn_cols(gpus[0].eng);
         // shards over the whole corpus; every GPU keeps its rows in one block behind a plan with the same geometry
@@ -572,17 +574,15 @@ int real_main(int argc, char **argv) {
             for (auto &e : errs)
                 if (!e.empty()) throw Fatal(e);
             // back to list order, then the writers
-            std::vector<std::pair<int, size_t>> where(items.size());  // (gpu, row offset in floats)
-            for (int g = 0; g < ngpu; g++) {
-                const int64_t *ro = ctu_plan_row_offsets(sh[g].plan);
-                for (size_t k = 0; k < sh[g].idx.size(); k++) where[sh[g].idx[k]] = {g, (size_t)ro[k] * d.row_floats};
-            }
+            std::vector<std::pair<int, size_t>> where(items.size());  // (gpu, position in that GPU's shard)
+            for (int g = 0; g < ngpu; g++)
+                for (size_t k = 0; k < sh[g].idx.size(); k++) where[sh[g].idx[k]] = {g, k};
             for (size_t i = 0; i < items.size(); i++) {
                 const int g = where[i].first;
+                const size_t k = where[i].second;
                 const int64_t *ro = ctu_plan_row_offsets(sh[g].plan);
-                const size_t k = std::find(sh[g].idx.begin(), sh[g].idx.end(), i) - sh[g].idx.begin();
                 const int64_t nr = ro[k + 1] - ro[k];
-                const float *r = sh[g].rows.data() + where[i].second;
+                const float *r = sh[g].rows.data() + (size_t)ro[k] * d.row_floats;
                 if (ark) ark->add(items[i].fout, r, nr, d.row_floats);
                 else if (pf) pf->add(r, nr, d.row_floats);
                 else write_htk(items[i].fout, r, nr, d);
