@@ -208,7 +208,7 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.post_order > 0) {
         if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "delta / stacking on non-cepstral kinds (the reference sizes the chain as fea_ncepcoefs+1, src/fea/fea_delta.cc:22-28)";
         if (!o.fea_c0) return "delta / stacking without -fea_c0 (the reference's writers leave slots of the row unwritten, src/io/out.cc:190-201)";
-        if (o.do_vad()) return "VAD together with delta / stacking (the detector would run on delayed and on flushed frames)";
+        if (o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea") return "the `fea` VAD criterion together with delta / stacking";
         int wsum = 0;
         for (int j = 0; j < d.post_order; j++) {
             if (d.post_w[j] > 16) return "delta / stacking window above 16 frames";
@@ -226,7 +226,6 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.cms) {
         if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "CMS on non-cepstral kinds (the reference walks fea_ncepcoefs+1 entries whatever the vector holds, src/fea/post_impl.cc:203-240)";
         if (d.post_stack) return "CMS on stacked vectors";
-        if (o.do_vad()) return "VAD together with CMS";
         if (d.cms == 2 && (o.length_b < 1 || o.length_b > 512)) return "block CMS window outside 1..512 frames";
         if (d.cms_cols > 32) return "more than 32 CMS columns";
         if (d.cms == 2 && (size_t)(64 + o.length_b - 1) * d.cms_cols * sizeof(float) > 64 * 1024) return "block CMS tile above 64 KiB of LDS";
@@ -294,7 +293,7 @@ bool plain_cepstral(const ctu::Design &d) {
 bool vf_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     return CTU_VF && CTU_MD && plain_cepstral(d) && o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" &&
-           d.wfft == 256 && o.vad_lpc_coefs == VF_NC && d.window == VF_WINDOW;
+           d.wfft == 256 && o.vad_lpc_coefs == VF_NC && d.window == VF_WINDOW && d.post_order == 0;
 }
 bool md_eligible(const ctu::Design &d) { return CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d)); }
 // hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 256-point mode, 200-sample window, the
@@ -887,6 +886,10 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             vp.qmaxinc = o.vad_dyn_qmaxinc; vp.qmaxdec = o.vad_dyn_qmaxdec; vp.qmindec = o.vad_dyn_qmindec; vp.qmininc = o.vad_dyn_qmininc;
             vp.perc_init = o.vad_perc_init; vp.adapt_init = o.vad_adapt_init; vp.dyn_init = o.vad_dyn_init;
             vp.D = d.D; vp.ncep = o.fea_ncepcoefs; vp.c0_slot = d.row_slot.empty() ? -1 : d.row_slot[0];
+            vp.delay = 0;
+            for (int j = 0; j < d.post_order; j++) vp.delay += d.post_w[j];
+            vp.e_slot = o.fea_E ? (d.post_order > 0 ? d.D - 1 : d.e_slot) : -1;
+            vp.e_delay = (o.vad_filter_order - 1) / 2;
         }
         HIP_TRY(hipEventCreate(&e->ev0));
         HIP_TRY(hipEventCreate(&e->ev1));
@@ -1280,9 +1283,6 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 }
 #undef BURG_LAUNCH
             }
-            if (!e->vf)  // the fused path replays the decisions in the wave that walks the utterance
-                hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
-                                   pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
             HIP_TRY(hipGetLastError());
         }
         if (d.kind == ctu::FeaKind::TrapDct) {
@@ -1346,6 +1346,13 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 hipLaunchKernelGGL(cms_block_kernel, dim3(pl->n_trap_chunks), dim3(256),
                                    (size_t)(64 + cp.L - 1) * cp.ncols * sizeof(float), s, pl->base_rows.p, d_rows,
                                    pl->utt_info.p, pl->trap_chunks.p, cp);
+            HIP_TRY(hipGetLastError());
+        }
+        if (e->do_vad && !e->vf) {
+            // After the post passes: the `fea` criterion reads the vector the writer sees (CMS applied), and the energy
+            // column is shifted in the finished rows.  The fused path replays the decisions in the wave that walks the utterance.
+            hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
+                               pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
             HIP_TRY(hipGetLastError());
         }
     } catch (const std::exception &ex) {

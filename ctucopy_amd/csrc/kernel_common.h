@@ -38,6 +38,10 @@ struct VadParams {
     double cep_p, abs_thr, perc_thr, adapt_q, adapt_za, dyn_perc, dyn_min, qmaxinc, qmaxdec, qmindec, qmininc;
     int perc_init, adapt_init, dyn_init;
     int D, ncep, c0_slot;        // cepdist-fea: where the internal vector sits in a written row
+    int delay;                   // delta / stacking ahead of the writer: the detector is called when a delayed vector comes out, on the
+                                 // criterion of the newest input frame min(call + delay, T - 1) (src/io/batch.cc:172-192,230-241,251-291)
+    int e_slot, e_delay;         // -fea_E: the writer reads the energy through a pointer when the median filter releases a
+                                 // vector, so row j carries the energy of row min(j + e_delay, T - 1); e_slot < 0: no such column
 };
 
 struct KParams {

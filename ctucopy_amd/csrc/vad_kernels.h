@@ -301,7 +301,7 @@ __device__ __forceinline__ void vad_flush(VadRun &r, const VadParams &vp, int T,
 
 // One wave per utterance: stages 64 frames of criterion inputs in LDS with coalesced loads, then replays them.
 __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
-                                                         const float *__restrict__ rows, const int64_t *__restrict__ row_off,
+                                                         float *__restrict__ rows, const int64_t *__restrict__ row_off,
                                                          int n_utt, uint8_t *__restrict__ vad_out, VadParams vp) {
     __shared__ double stage[64 * 32];
     const int u = blockIdx.x, lane = threadIdx.x;
@@ -315,9 +315,12 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
         const int nt = min(64, T - tb);
         __syncthreads();
         if (vp.cri == 0) {
-            if (lane < nt) stage[lane] = cri_energy[r0 + tb + lane];
+            if (lane < nt) stage[lane] = cri_energy[r0 + min(tb + lane + vp.delay, T - 1)];
         } else if (vp.cri == 1) {
-            for (int e = lane; e < nt * nc; e += 64) stage[e] = ci_all[(r0 + tb) * nc + e];
+            for (int e = lane; e < nt * nc; e += 64) {
+                const int f = e / nc, i = e - f * nc;
+                stage[e] = ci_all[(r0 + min(tb + f + vp.delay, T - 1)) * nc + i];
+            }
         } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131)
             for (int e = lane; e < nt * nc; e += 64) {
                 const int f = e / nc, i = e - f * nc;
@@ -333,6 +336,16 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
         }
     }
     vad_flush(run, vp, T, lane, vad_out + r0);
+    if (vp.e_slot >= 0 && vp.e_delay > 0) {  // energy column: forward shift in place, 64 rows at a time (reads run ahead of the writes)
+        for (int tb = 0; tb < T; tb += 64) {
+            const int j = tb + lane;
+            float ev = 0.f;
+            if (j < T) ev = rows[(r0 + min(j + vp.e_delay, T - 1)) * vp.D + vp.e_slot];
+            __syncthreads();
+            if (j < T) rows[(r0 + j) * vp.D + vp.e_slot] = ev;
+            __syncthreads();
+        }
+    }
 }
 
 }  // namespace

@@ -828,11 +828,6 @@ static int design_all(ctuo_t *c) {
         for (int j = 0; j < o->n_order; j++)
             if (w[j] < 1) { set_err(c, o->fea_trap ? "FEA: Trap window size must be >= 3!" : "FEA: Delta window size must be > 1!"); return -1; }
         c->Xsize = o->fea_trap ? fea_c * (2 * o->d_win + 1) : fea_c * (o->n_order + 1);
-        if (c->do_vad) { set_err(c, "oracle: VAD together with delta / stacking is not restated (the detector would run on delayed and on flushed frames, batch.cc:230-241,251-291)"); return -1; }
-    }
-    if ((o->fea_Z_exp > 0 || o->fea_Z_block > 0) && c->do_vad) {
-        set_err(c, "oracle: VAD together with CMS is not restated");
-        return -1;
     }
     int size = c->Xsize;
     if (!strcmp(k, "lpa")) size -= 1;
@@ -1371,10 +1366,13 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     vad_state_t vs;
     memset(&vs, 0, sizeof vs);
     const int do_vad = c->do_vad, order = o->vad_filter_order, hdelay = (order - 1) / 2;
+    const int vlen = c->Xsize > c->nfea ? c->Xsize : c->nfea; /* the vector the VAD's ring delays is the one OUT sees (batch.cc:76,122-130) */
+    double cur_en = 0.0;      /* energy criterion of the newest input frame */
+    double *en_t = NULL, *ci_t = NULL; /* delta / stacking: the criteria of every input frame, for the replay below */
     double *hw1 = NULL, *hw2 = NULL, *tsig = NULL, *hre = NULL, *him = NULL;
     if (do_vad) {
         vs.history = calloc(order, sizeof(int));
-        vs.ring = calloc((size_t)order * c->nfea, sizeof(double));
+        vs.ring = calloc((size_t)order * vlen, sizeof(double));
         if (!strcmp(o->vad_cri_mode, "cepdist")) {
             vs.csize = !strcmp(o->vad_cepdist_mode, "lpc") ? o->vad_lpc_coefs : c->nfea;
             vs.c0 = calloc(vs.csize, sizeof(double));
@@ -1396,6 +1394,50 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     double preemtmp = 0.; /* in.cc:274 */
     long nrows = 0, nvad = 0;
     int fail = 0;
+
+    if (is_post && do_vad) {
+        en_t = calloc((size_t)(T > 0 ? T : 1), sizeof(double));
+        if (vs.csize && !strcmp(o->vad_cepdist_mode, "lpc")) ci_t = calloc((size_t)(T > 0 ? T : 1) * vs.csize, sizeof(double));
+    }
+    /* One call of BATCH::save_frame with the VAD on (batch.cc:230-241): VAD::process_frame (vad.cc:692-703) on the criterion
+     * of the newest INPUT frame (cur_en / vs.ci; the `fea` mode takes the vector OUT sees), threshold, consume_vad, median
+     * filter with its ring of output vectors (vad.h:126-150), then the writer.  TC = number of calls so far (the VAD's
+     * frame_index), FV = the vector OUT sees at this call, EV = the energy the writer reads through its pointer. */
+#define VAD_CALL(TC, FV, EV) do {                                                                                              \
+        double cri_;                                                                                                           \
+        if (!strcmp(o->vad_cri_mode, "energy")) cri_ = cur_en;                                                                 \
+        else {                                                                                                                 \
+            if (!strcmp(o->vad_cepdist_mode, "fea")) for (int i_ = 0; i_ < vs.csize; i_++) vs.ci[i_] = (FV)[i_];                \
+            if ((TC) == 0) {                                                                                                   \
+                for (int i_ = 0; i_ < vs.csize; i_++) vs.c0[i_] = vs.ci[i_];                                                   \
+                cri_ = 0.0;                                                                                                    \
+            } else {                                                                                                           \
+                if ((TC) == 1) for (int i_ = 0; i_ < vs.csize; i_++) vs.c0[i_] = (vs.c0[i_] + vs.ci[i_]) / 2.0;                \
+                double sum_ = 0.0;                                                                                             \
+                for (int i_ = 1; i_ < vs.csize; i_++) sum_ += (vs.ci[i_] - vs.c0[i_]) * (vs.ci[i_] - vs.c0[i_]);               \
+                cri_ = 4.3429 * sqrt(2 * sum_);                                                                                \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        int vad0_ = thr_process(o, &vs, (int)(TC), cri_);                                                                      \
+        if (vs.c0 && !(vad0_ && ((TC) > o->vad_cepdist_init))) /* consume_vad, vad.cc:288-294 */                               \
+            for (int i_ = 0; i_ < vs.csize; i_++) vs.c0[i_] = o->vad_cepdist_p * vs.c0[i_] + (1.0 - o->vad_cepdist_p) * vs.ci[i_]; \
+        vs.history[vs.hidx] = vad0_;                                                                                           \
+        memcpy(vs.ring + (size_t)vs.hidx * vlen, (FV), sizeof(double) * vlen);                                                 \
+        vs.hidx = (vs.hidx + 1) % order;                                                                                       \
+        if (vs.hsize < hdelay) { vs.hsize++; break; } /* not ready: nothing saved (batch.cc:235-236) */                        \
+        vs.ready = 1;                                                                                                          \
+        double hs_ = 0.0;                                                                                                      \
+        for (int i_ = 0; i_ < order; i_++) hs_ += vs.history[i_] ? 1.0 : 0.0;                                                  \
+        const double *fo_ = vs.ring + (size_t)(vs.start % order) * vlen;                                                       \
+        vs.start++;                                                                                                            \
+        int dec_ = (hs_ / (double)order) >= 0.5;                                                                               \
+        if (vadout && strcmp(o->vad_out_mode, "none")) vadout[nvad] = dec_ ? '1' : '0';                                        \
+        nvad++;                                                                                                                \
+        if (!(!dec_ && !strcmp(o->vad_apply_mode, "drop"))) {                                                                  \
+            emit_row(c, fo_, (EV), rows + (size_t)nrows * c->D);                                                               \
+            nrows++;                                                                                                           \
+        }                                                                                                                      \
+    } while (0)
 
     for (long t = 0; t < T && !fail; t++) {
         const long s = t * (long)wshift;
@@ -1620,9 +1662,28 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
             continue;
         }
 
+        if (do_vad && !is_trap) {
+            /* criterion inputs of this input frame: VADcri_energy (vad.cc:96-107) / VADcri_cepdist lpc (vad.cc:220-276) */
+            if (!strcmp(o->vad_cri_mode, "energy")) {
+                double en = 0.0;
+                for (int i = 0; i < K; i++) en += Xabs[i] * Xabs[i];
+                if (o->vad_energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
+                cur_en = en;
+            } else if (!strcmp(o->vad_cri_mode, "cepdist")) {
+                if (!strcmp(o->vad_cepdist_mode, "lpc")) {
+                    for (int i = 0; i < K; i++) { hre[i] = Xabs[i] * cos(Xph[i]); him[i] = Xabs[i] * sin(Xph[i]); }
+                    hc2r(hre, him, wfft, tsig, hw1, hw2);
+                    ctuo_burg_cepstrum(tsig, window, vs.csize, NULL, vs.ci, NULL);
+                } else if (strcmp(o->vad_cepdist_mode, "fea")) { set_err(c, "VADcri_cepdist: vad_cepdist_mode=in and in->_fvec is not available!"); fail = 1; break; }
+            } else { set_err(c, "VAD: unknown vad_cri_mode!"); fail = 1; break; }
+        }
         if (is_post) { /* deltaFEA chain replayed after the loop (it only consumes fvec and E) */
             memcpy(postbuf + (size_t)t * c->nfea, fvec, sizeof(double) * c->nfea);
             postE[t] = E_out;
+            if (do_vad) { /* the detector is called when a delayed vector comes out, on the newest input frame's criterion */
+                en_t[t] = cur_en;
+                if (ci_t) memcpy(ci_t + (size_t)t * vs.csize, vs.ci, sizeof(double) * vs.csize);
+            }
             continue;
         }
 
@@ -1634,53 +1695,8 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
             nrows++;
             continue;
         }
-        /* VAD::process_frame, vad.cc:692-703 */
-        double cri;
-        if (!strcmp(o->vad_cri_mode, "energy")) { /* vad.cc:96-107 */
-            double en = 0.0;
-            for (int i = 0; i < K; i++) en += Xabs[i] * Xabs[i];
-            if (o->vad_energy_db) en = 10.0 * log10(2.2250738585072014e-308 + en);
-            cri = en;
-        } else if (!strcmp(o->vad_cri_mode, "cepdist")) { /* vad.cc:220-276 */
-            if (!strcmp(o->vad_cepdist_mode, "lpc")) {
-                for (int i = 0; i < K; i++) { hre[i] = Xabs[i] * cos(Xph[i]); him[i] = Xabs[i] * sin(Xph[i]); }
-                hc2r(hre, him, wfft, tsig, hw1, hw2);
-                ctuo_burg_cepstrum(tsig, window, vs.csize, NULL, vs.ci, NULL);
-            } else if (!strcmp(o->vad_cepdist_mode, "fea")) {
-                for (int i = 0; i < vs.csize; i++) vs.ci[i] = fvec[i];
-            } else { set_err(c, "VADcri_cepdist: vad_cepdist_mode=in and in->_fvec is not available!"); fail = 1; break; }
-            if (t == 0) {
-                for (int i = 0; i < vs.csize; i++) vs.c0[i] = vs.ci[i];
-                cri = 0.0;
-            } else {
-                if (t == 1) for (int i = 0; i < vs.csize; i++) vs.c0[i] = (vs.c0[i] + vs.ci[i]) / 2.0;
-                double sum = 0.0;
-                for (int i = 1; i < vs.csize; i++) sum += (vs.ci[i] - vs.c0[i]) * (vs.ci[i] - vs.c0[i]);
-                cri = 4.3429 * sqrt(2 * sum);
-            }
-        } else { set_err(c, "VAD: unknown vad_cri_mode!"); fail = 1; break; }
-        int vad0 = thr_process(o, &vs, (int)t, cri);
-        if (vs.c0 && !(vad0 && (t > o->vad_cepdist_init))) /* consume_vad, vad.cc:288-294 */
-            for (int i = 0; i < vs.csize; i++) vs.c0[i] = o->vad_cepdist_p * vs.c0[i] + (1.0 - o->vad_cepdist_p) * vs.ci[i];
-        /* medianFilter::push, vad.h:126-150 */
-        vs.history[vs.hidx] = vad0;
-        memcpy(vs.ring + (size_t)vs.hidx * c->nfea, fvec, sizeof(double) * c->nfea);
-        vs.hidx = (vs.hidx + 1) % order;
-        if (vs.hsize < hdelay) { vs.hsize++; continue; } /* not ready: nothing saved (batch.cc:235-236) */
-        vs.ready = 1;
-        {
-            double sum = 0.0;
-            for (int i = 0; i < order; i++) sum += vs.history[i] ? 1.0 : 0.0;
-            const double *fo = vs.ring + (size_t)(vs.start % order) * c->nfea;
-            vs.start++;
-            int dec = (sum / (double)order) >= 0.5;
-            if (vadout && strcmp(o->vad_out_mode, "none")) vadout[nvad] = dec ? '1' : '0';
-            nvad++;
-            if (!(!dec && !strcmp(o->vad_apply_mode, "drop"))) {
-                emit_row(c, fo, E_out, rows + (size_t)nrows * c->D);
-                nrows++;
-            }
-        }
+        if (cms.type) cms_apply(&cms, o, fvec); /* BATCH::cmvn_stat, batch.cc:198-200: post, then save (the VAD sees the vector after it) */
+        VAD_CALL(t, fvec, E_out);
     }
 
     if (!fail && is_trap) {
@@ -1732,10 +1748,23 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         if (n >= 3) dstage_init(&st[2], o, st[1].out, 4, o->t_win);
         const double *X = st[n - 1].out;
         double E_cur = -1.;
-#define POST_EMIT() do { if (cms.type) cms_apply(&cms, o, (double *)X); emit_row(c, X, E_cur, rows + (size_t)nrows * c->D); nrows++; } while (0)
+        long tcur = 0, ncall = 0; /* newest input frame; save_frame calls so far (the VAD's frame_index) */
+#define POST_EMIT() do {                                                                                   \
+        if (cms.type) cms_apply(&cms, o, (double *)X);                                                     \
+        if (do_vad) {                                                                                      \
+            cur_en = en_t[tcur];                                                                           \
+            if (ci_t) memcpy(vs.ci, ci_t + (size_t)tcur * vs.csize, sizeof(double) * vs.csize);            \
+            VAD_CALL(ncall, X, E_cur);                                                                     \
+            ncall++;                                                                                       \
+        } else {                                                                                           \
+            emit_row(c, X, E_cur, rows + (size_t)nrows * c->D);                                            \
+            nrows++;                                                                                       \
+        }                                                                                                  \
+    } while (0)
         for (long t = 0; t < T; t++) {
             memcpy(in0, postbuf + (size_t)t * c->nfea, sizeof(double) * c->nfea);
             E_cur = postE[t];
+            tcur = t;
             if (!dstage_process(&st[0])) continue;
             if (n >= 2) {
                 if (!dstage_process(&st[1])) continue;
@@ -1760,6 +1789,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
 #undef POST_EMIT
         for (int j = 0; j < n; j++) dstage_free(&st[j]);
         free(in0);
+        E_last = postE[T - 1];
     }
 
     if (!fail && do_vad && !is_trap) { /* BATCH::flush_vad, batch.cc:243-249; medianFilter::flush_frame, vad.h:156-175 */
@@ -1768,7 +1798,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
             vs.hidx = (vs.hidx + 1) % order;
             double sum = 0.0;
             for (int i = 0; i < order; i++) sum += vs.history[i] ? 1.0 : 0.0;
-            const double *fo = vs.ring + (size_t)(vs.start % order) * c->nfea;
+            const double *fo = vs.ring + (size_t)(vs.start % order) * vlen;
             vs.start++;
             int dec = (sum / (double)order) >= 0.5;
             vs.hsize--;
@@ -1785,7 +1815,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
 
     free(x); free(fft_in); free(Xre); free(Xim); free(zr); free(zi); free(Xabs); free(Xph); free(Y); free(fvec);
     ctuo_cepdet_free(ss_det); free(ss_nr); free(ss_re); free(ss_im); free(ss_t); free(ss_w1); free(ss_w2);
-    free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin); free(postbuf); free(postE);
+    free(Navg); free(Yavg); free(trapbuf); free(trapE); free(tin); free(postbuf); free(postE); free(en_t); free(ci_t);
     cms_free(&cms);
     free(ola); free(ytime); free(sw1); free(sw2); free(sre); free(sim);
     free(RRe); free(rc); free(a); free(aa); free(P);

@@ -188,6 +188,33 @@ def test_fft_sizes_above_512(Engine):
     _check(Engine, "-fs 48000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 64 -s 20".split(), u44)   # 3072 -> 4096
 
 
+def test_vad_with_energy_column_cms_and_delta(Engine):
+    # src/io/batch.cc:172-241: the detector is called when a vector reaches the writer - after CMS, and with a delta /
+    # stacking chain on the criterion of the newest INPUT frame (delayed vectors, flushed frames); the writer reads the
+    # energy through a pointer when the median filter releases a vector (the column runs ahead of the rows)
+    from tests.util import C4
+    v16 = "-vad_out_mode vad -vad_cri_mode energy".split()
+    u16 = [synth_utt(130 + i, 14000 + 3333 * i) for i in range(3)] + [sig("CS0")[:30000]]
+    u8 = [synth_utt(140 + i, 9000 + 2222 * i, fs=8000) for i in range(2)] + [sig("CS3")[:30000]]
+    for cfg, utts in [(C2 + v16 + ["-fea_E", "on"], u16),
+                      (C2 + v16 + ["-fea_E", "on", "-vad_filter_order", "7", "-vad_apply_mode", "drop"], u16),
+                      (C2 + v16 + ["-fea_Z_exp", "2000", "-vad_apply_mode", "drop"], u16),
+                      (C2 + v16 + ["-fea_Z_block", "500"], u16),
+                      (C2 + ["-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-fea_Z_exp", "1500"], u16),
+                      (C2 + v16 + ["-fea_delta", "d_a", "-fea_E", "on"], u16),
+                      (C2 + v16 + ["-fea_delta", "d_a_t", "-vad_apply_mode", "drop"], u16),
+                      (C2 + v16 + ["-fea_trap", "9"], u16),
+                      (C4 + ["-fea_delta", "d_a"], u8),
+                      (C4 + ["-fea_Z_exp", "2000", "-vad_apply_mode", "drop"], u8)]:
+        rows, vads = Engine(cfg).extract(utts, want_vad=True)
+        orc = Oracle(cfg)
+        for u, r, v in zip(utts, rows, vads):
+            ref, rv = orc.process(u, want_vad=True)
+            assert np.array_equal(v, rv), " ".join(cfg)
+            assert r.shape == ref.shape, " ".join(cfg)
+            _assert_rows(r, ref, cfg)
+
+
 def test_exten_16k(Engine):
     cfg = C2 + ["-nr_mode", "exten", "-nr_a", "2"]
     _check(Engine, cfg, [sig("CS3"), synth_utt(51, 40000), synth_utt(52, 9000)])
