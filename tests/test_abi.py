@@ -81,7 +81,11 @@ def test_unsupported_configurations_are_reported_not_approximated():
     for cfg in (C2 + ["-dither", "1.0"], C2 + ["-nr_mode", "hwss", "-vad", "burg"], C2 + ["-stat_cmvn", "stat.txt", "-fea_c0", "off"], C2 + ["-apply_cmvn", "s", "-fea_Z_exp", "500"],
                 C2 + ["-fea_kind", "spec", "-fea_Z_exp", "500"],
                 C2 + ["-fea_delta", "d_a", "-fea_c0", "off"], C2 + ["-fea_kind", "logspec", "-fea_delta", "d"],
-                C2 + ["-fea_delta", "d", "-d_win", "17"], C4 + ["-fea_delta", "d"]):
+                C2 + ["-fea_delta", "d", "-d_win", "17"],
+                C2 + "-vad_out_mode vad -vad_cri_mode cepdist -vad_cepdist_mode fea -fea_delta d".split(),   # the `fea` criterion on delayed vectors
+                C2 + ["-w", "300"],                               # 4800 samples: an 8192-point FFT
+                C2 + ["-w", "40", "-nr_mode", "exten"],           # noise reduction with a 1024-point FFT
+                C2 + ["-remove_dc1", "on", "-w", "25", "-s", "2"]):   # 12 frames over a sample
         with pytest.raises(CtuError) as ei:
             ctucopy_amd.Engine(cfg)
         assert ei.value.code == ceng.CTU_ERR_UNSUPPORTED
