@@ -693,3 +693,64 @@ def test_g711_decode_on_the_device_matches_the_reference_table(Engine):
         codes = rng.integers(0, 256, 4099, dtype=np.uint8)
         dev = torch.from_numpy(codes).cuda()
         assert np.array_equal(eng.decode_g711(dev[3:], alaw=alaw).cpu().numpy(), table[codes[3:]])
+
+
+@pytest.mark.parametrize("name", ["configs1_smfcc", "configs3_snoisy"])
+def test_baseline_sizes_by_properties(Engine, name):
+    """BASELINE.json's full sizes (10 000 synthetic utterances on one GPU), checked through what does not need the oracle on
+    nine million frames: every row finite, a sample of utterances against the oracle, rows and VAD bytes bit-identical to
+    the same utterances run as a batch of their own (an utterance's result does not depend on its neighbours, on the tile
+    chains or on the wave that walked it), and shift equivariance (dropping one hop of samples drops exactly one row)."""
+    import torch
+    from ctucopy_amd import synth
+    from tests.util import C4
+    cfg, set_id = (C2, synth.SET_SPEECH) if name == "configs1_smfcc" else (C4, synth.SET_NOISY)
+    eng = Engine(cfg)
+    n = 10000
+    idx = np.arange(n)
+    lens = synth.lengths(set_id, idx)
+    plan = eng.plan(lens)
+    host = synth.fill_arena(set_id, idx, plan.sample_off, plan.total_samples)
+    dev = torch.device("cuda", 0)
+    pcm = torch.from_numpy(host).to(dev)
+    vad = torch.zeros(max(plan.total_frames, 1), dtype=torch.uint8, device=dev) if eng.dims.has_vad else None
+    rows = eng.run_device(plan, pcm, vad=vad)
+    torch.cuda.synchronize()
+    assert rows.shape[0] == plan.total_frames == int(((lens - (eng.dims.window - eng.dims.wshift)) // eng.dims.wshift).sum())
+    assert bool(torch.isfinite(rows).all().item())
+    rows_h = rows.cpu().numpy()
+    vad_h = vad.cpu().numpy() if vad is not None else None
+    orc = Oracle(cfg)
+    rng = np.random.default_rng(3)
+    for k in rng.choice(n, 3, replace=False):
+        u = host[plan.sample_off[k]:plan.sample_off[k] + lens[k]]
+        if vad_h is None:
+            ref = orc.process(u)
+        else:
+            ref, rv = orc.process(u, want_vad=True)
+            assert np.array_equal(vad_h[plan.row_off[k]:plan.row_off[k + 1]], rv)
+        _assert_rows(rows_h[plan.row_off[k]:plan.row_off[k + 1]], ref, cfg)
+    # the same utterances as a batch of their own: bit-identical
+    pick = np.sort(rng.choice(n, 64, replace=False))
+    utts = [host[plan.sample_off[k]:plan.sample_off[k] + lens[k]].copy() for k in pick]
+    if vad_h is None:
+        alone = eng.extract(utts)
+    else:
+        alone, valone = eng.extract(utts, want_vad=True)
+    for j, k in enumerate(pick):
+        assert np.array_equal(alone[j], rows_h[plan.row_off[k]:plan.row_off[k + 1]]), k
+        if vad_h is not None:
+            assert np.array_equal(valone[j], vad_h[plan.row_off[k]:plan.row_off[k + 1]]), k
+    # eight hops fewer samples at the front: the rows from the second on are those of the original from the tenth on,
+    # bit for bit (the first row starts from an empty pre-emphasis history; a step of the kernel is eight frames and its two
+    # halves are separate instruction streams whose roundings may differ in the last bit, so the shift keeps a frame's place
+    # within the step; stateless chains only)
+    if name == "configs1_smfcc":
+        k = int(pick[0])
+        u = host[plan.sample_off[k]:plan.sample_off[k] + lens[k]]
+        shifted = eng.extract([u[8 * eng.dims.wshift:].copy()])[0]
+        full = rows_h[plan.row_off[k]:plan.row_off[k + 1]]
+        assert shifted.shape[0] == full.shape[0] - 8 and np.array_equal(shifted[1:], full[9:])
+        one = eng.extract([u[eng.dims.wshift:].copy()])[0]   # any shift: the same rows to rounding
+        assert one.shape[0] == full.shape[0] - 1 and rel_err(one[1:], full[2:]) <= TOL
+    plan.close()
