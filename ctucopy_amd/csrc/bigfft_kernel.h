@@ -16,8 +16,9 @@ struct BigParams {
     int n_tiles;
     const float *win;        // [window] Hamming
     const float2 *tw;        // [wfft/2] W_wfft^m = (cos, -sin)(2 pi m / wfft)
-    const float *fbw;        // [B][K] dense filter bank
-    const int *fb_range;     // [B][2] first / last non-zero bin
+    const float *fbw;        // the bands' non-zero runs one after the other (fb_total floats)
+    const int *fb_range;     // [B][3] first / last non-zero bin, offset of the run in fbw
+    int fb_total;
     const float *coef;       // dctc: [ncoef_out][B] rows in writer order (norm and lifter folded in); lp: [lporder+1][B] as doubles below
     const double *coef_d;    // lp: cosine iDFT rows in double [lporder+1][B]
     const float *lifter;     // [ncep]
@@ -35,6 +36,7 @@ __device__ __forceinline__ double block_sum(double v, double *red) {  // 256 thr
     return red[0] + red[1] + red[2] + red[3];
 }
 
+template <int NIT>  // wfft / 256: 4, 8 or 16 samples per lane
 __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
     extern __shared__ __align__(16) float smem[];
     const int N = p.wfft, Nc = N >> 1, K = p.K;
@@ -43,26 +45,57 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
     float *P = reinterpret_cast<float *>(Bf + Nc);     // [K] (+3 padding)
     float *Y = P + ((K + 3) & ~3);                     // [64] band values
     double *red = reinterpret_cast<double *>(Y + 64);  // [4]
+    // tables, staged once per workgroup: twiddles [Nc], window [window rounded up to 4], filter-bank runs [fb_total]
+    float2 *ltw = reinterpret_cast<float2 *>(red + 4);
+    float *lwin = reinterpret_cast<float *>(ltw + Nc);
+    float *lfb = lwin + ((p.window + 3) & ~3);
+    // coefficient rows of the tail (a loop over global memory would pay an L2 round trip per band): dctc [ncoef_out][B]
+    // floats, lp [lporder+1][B] doubles; band ranges [B][3]; band logarithms [64]
+    double *lcoef_d = reinterpret_cast<double *>(lfb + ((p.fb_total + 3) & ~3));
+    const int ncd = (p.feat == FEAT_LP) ? (p.lporder + 1) * p.B : 0, ncf = (p.feat == FEAT_DCTC) ? p.ncoef_out * p.B : 0;
+    float *lcoef = reinterpret_cast<float *>(lcoef_d + ncd);
+    int *lrange = reinterpret_cast<int *>(lcoef + ((ncf + 3) & ~3));
+    float *Ylog = reinterpret_cast<float *>(lrange + ((3 * p.B + 3) & ~3));
     const int tid = threadIdx.x;
+    for (int i = tid; i < Nc; i += 256) ltw[i] = p.tw[i];
+    for (int i = tid; i < p.window; i += 256) lwin[i] = p.win[i];
+    for (int i = tid; i < p.fb_total; i += 256) lfb[i] = p.fbw[i];
+    for (int i = tid; i < ncd; i += 256) lcoef_d[i] = p.coef_d[i];
+    for (int i = tid; i < ncf; i += 256) lcoef[i] = p.coef[i];
+    for (int i = tid; i < 3 * p.B; i += 256) lrange[i] = p.fb_range[i];
+    __syncthreads();
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const TileRec rec = load_rec(p.tiles, tile);
-        for (int f = 0; f < rec.nvalid; f++) {
+        // the samples of a frame are fetched one frame ahead (registers): the loads fly under the previous frame's passes
+        int16_t cur[NIT], prv[NIT];
+        auto fetch = [&](int f) {
             const int16_t *x = p.pcm + rec.sbase + (int64_t)f * p.wshift;
             const bool file_start = rec.t0 + f == 0;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int i = tid + 256 * it;
+                cur[it] = i < p.window ? x[i] : (int16_t)0;
+                prv[it] = (i < p.window && !(i == 0 && file_start)) ? x[i - 1] : (int16_t)0;
+            }
+        };
+        fetch(0);
+        for (int f = 0; f < rec.nvalid; f++) {
             // ---- pre-emphasis x window (src/io/in.cc:364-372), packed as z[n] = y[2n] + i y[2n+1]
             float *yb = reinterpret_cast<float *>(A);
             double part = 0.0, raw = 0.0;
-            for (int i = tid; i < N; i += 256) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int i = tid + 256 * it;
                 float y = 0.f;
                 if (i < p.window) {
-                    const float xi = (float)x[i];
-                    const float xm = (i == 0 && file_start) ? 0.f : (float)x[i - 1];
-                    y = p.win[i] * (xi - p.preem * xm);
+                    const float xi = (float)cur[it];
+                    y = lwin[i] * (xi - p.preem * (float)prv[it]);
                     part += (double)y;
                     if (i >= 1) raw += (double)xi * (double)xi;
                 }
                 yb[i] = y;
             }
+            if (f + 1 < rec.nvalid) fetch(f + 1);
             if (p.remove_dc) {  // src/io/in.cc:375-382
                 const float m = (float)(block_sum(part, red) / (double)p.window);
                 for (int i = tid; i < p.window; i += 256) yb[i] -= m;
@@ -76,7 +109,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 const int tstep = Nc / Ns;  // W_{2Ns}^k = W_wfft^(k * Nc / Ns)
                 for (int j = tid; j < (Nc >> 1); j += 256) {
                     const int k = j & (Ns - 1);
-                    const float2 w = p.tw[k * tstep];
+                    const float2 w = ltw[k * tstep];
                     const float2 a = src[j], b0 = src[j + (Nc >> 1)];
                     const float2 b = make_float2(b0.x * w.x - b0.y * w.y, b0.x * w.y + b0.y * w.x);
                     const int j0 = ((j - k) << 1) + k;
@@ -98,7 +131,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                     const float v = src[0].x - src[0].y;
                     pw = v * v;
                 } else {
-                    const float2 a = src[k], c = src[Nc - k], w = p.tw[k];
+                    const float2 a = src[k], c = src[Nc - k], w = ltw[k];
                     const float sr = a.x + c.x, si = a.y - c.y, dr = a.x - c.x, di = a.y + c.y;
                     // X = (s - i W d) / 2 with W = (w.x, w.y): -i W d = (w.x di + w.y dr, w.y di - w.x dr) ... conj convention of tw = (cos, -sin)
                     const float tr = w.x * di + w.y * dr, ti = w.y * di - w.x * dr;
@@ -119,14 +152,17 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 const int b = tid >> 2, q = tid & 3;
                 float acc = 0.f;
                 if (b < p.B) {
-                    const int k0 = p.fb_range[2 * b], k1 = p.fb_range[2 * b + 1];
-                    const float *w = p.fbw + (size_t)b * K;
+                    const int k0 = lrange[3 * b], k1 = lrange[3 * b + 1];
+                    const float *w = lfb + lrange[3 * b + 2] - k0;
                     for (int k = k0 + q; k <= k1; k += 4) acc += w[k] * P[k];
                 }
                 acc += __shfl_xor(acc, 1);
                 acc += __shfl_xor(acc, 2);
                 if (p.fb_inld) acc = __builtin_amdgcn_exp2f(0.33f * __builtin_amdgcn_logf(acc));
-                if (q == 0 && b < 64) Y[b] = b < p.B ? acc : 0.f;
+                if (q == 0 && b < 64) {
+                    Y[b] = b < p.B ? acc : 0.f;
+                    Ylog[b] = b < p.B ? __builtin_amdgcn_logf(acc) * 0.69314718056f : 0.f;
+                }
             }
             __syncthreads();
             const int64_t row = rec.rbase + f;
@@ -137,12 +173,12 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
             if (p.feat == FEAT_BANDS) {
                 float *dst_ = p.band_to_scratch ? p.logmel : p.rows;
                 const int out_w = p.band_to_scratch ? p.B : p.D;
-                if (tid < p.B) dst_[row * out_w + tid] = p.band_log ? __builtin_amdgcn_logf(Y[tid]) * 0.69314718056f : Y[tid];
+                if (tid < p.B) dst_[row * out_w + tid] = p.band_log ? Ylog[tid] : Y[tid];
             } else if (p.feat == FEAT_DCTC) {
                 if (tid < p.ncoef_out && p.row_slot[tid] >= 0) {
-                    const float *c = p.coef + (size_t)tid * p.B;
+                    const float *c = lcoef + tid * p.B;
                     float acc = 0.f;
-                    for (int b = 0; b < p.B; b++) acc += c[b] * (__builtin_amdgcn_logf(Y[b]) * 0.69314718056f);
+                    for (int b = 0; b < p.B; b++) acc += c[b] * Ylog[b];
                     p.rows[row * p.D + tid] = acc;
                 }
             } else if (tid == 0) {
@@ -153,7 +189,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                     double r = 0.0;
                     for (int b = 0; b < p.B; b++) {
                         const double y = p.fb_inld ? (double)Y[b] : (double)Y[b] * (double)Y[b];
-                        r += p.coef_d[(size_t)k * p.B + b] * y;
+                        r += lcoef_d[k * p.B + b] * y;
                     }
                     R[k] = r;
                 }

@@ -94,6 +94,7 @@ struct ctu_engine {
     DevBuf<int> itab;
     // FFT sizes of 1024 to 4096 points (bigfft_kernel.h)
     bool big = false;
+    int big_fb_total = 0;
     DevBuf<float> big_win, big_fbw, big_coef, big_lifter;
     DevBuf<float2> big_tw;
     DevBuf<int> big_range, big_slot;
@@ -195,6 +196,7 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (o.remove_dc1) {
         if (d.window / d.wshift > 8) return "-remove_dc1 with more than 8 frames over a sample (window / shift above 8)";
         if (o.fea_E && o.fea_rawenergy) return "-remove_dc1 together with -fea_rawenergy";
+        if (o.do_vad() && !(o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea")) return "-remove_dc1 together with a VAD criterion on the spectrum";
     }
     if (o.nr_mode != "none" && o.nr_mode != "exten") {
         if (o.vadmode == "file") return "-vad file=...: one byte stream for all files, every byte but NUL counts as speech (src/nr/nr.cc:297-301)";
@@ -530,13 +532,16 @@ void build_big_tables(ctu_engine *e) {
         tw[m] = make_float2((float)std::cos(a), (float)-std::sin(a));
     }
     e->big_tw.upload(tw);
-    std::vector<float> fbw((size_t)d.B * d.K, 0.f);
-    std::vector<int> range((size_t)d.B * 2);
+    std::vector<float> fbw;
+    std::vector<int> range((size_t)d.B * 3);
     for (int b = 0; b < d.B; b++) {
-        for (int k = d.fb_first[b]; k <= d.fb_last[b]; k++) fbw[(size_t)b * d.K + k] = (float)d.fb[b][k];
-        range[2 * b] = d.fb_first[b];
-        range[2 * b + 1] = d.fb_last[b];
+        range[3 * b] = d.fb_first[b];
+        range[3 * b + 1] = d.fb_last[b];
+        range[3 * b + 2] = (int)fbw.size();
+        for (int k = d.fb_first[b]; k <= d.fb_last[b]; k++) fbw.push_back((float)d.fb[b][k]);
     }
+    e->big_fb_total = (int)fbw.size();
+    if (fbw.empty()) fbw.push_back(0.f);
     e->big_fbw.upload(fbw);
     e->big_range.upload(range);
     e->ncoef_out = 0;
@@ -688,9 +693,9 @@ void launch_nz(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     else if (feat == FEAT_DCTC && !wide) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, VX, 16, GEN>, grid, s, kp);
     else if (feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, VX, MAXC, GEN>, grid, s, kp);
     else if (feat == FEAT_LPD) {
-        if constexpr (GEN == GEN_FULL) {
-            if (!wide) launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, VX, 16, GEN_FULL>, grid, s, kp);
-            else launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, VX, MAXC, GEN_FULL>, grid, s, kp);
+        if constexpr (GEN == GEN_FULL || GEN == GEN_DC1) {
+            if (!wide) launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, VX, 16, GEN>, grid, s, kp);
+            else launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, VX, MAXC, GEN>, grid, s, kp);
         } else throw std::runtime_error("internal: the double LP tail has run-time flags only");
     }
     else if (!wide) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, VX, 16, GEN>, grid, s, kp);
@@ -708,7 +713,13 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.remove_dc1 && !kp.dbg && !kp.skip_phase2 && !kp.nr_after_fb;
     const bool narrow = kp.CW == 16;
     if (e->sy && kp.skip_phase2) {
-        launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, false, true>, grid, s, kp);
+        if (kp.remove_dc1) {
+            if constexpr (NZ == 16) launch_fe(e, &frontend_kernel<16, FEAT_BANDS, MODE, false, 16, GEN_DC1, 0, false, false, false, true>, grid, s, kp);
+        }
+        else launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, false, true>, grid, s, kp);
+    }
+    else if (kp.remove_dc1) {  // the generic row count only (ctu_engine_run picks NZ = 16), no spectrum export
+        if constexpr (NZ == 16) launch_nz<16, MODE, false, GEN_DC1>(e, grid, s, kp);
     }
     else if (e->ss) {
         if constexpr (MODE == 1) {
@@ -1194,7 +1205,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         }
         HIP_TRY(hipEventRecord(e->ev0, s));
         auto launch = [&] {
-            switch (e->nz) {
+            switch (kp.remove_dc1 ? 16 : e->nz) {
                 case 13: e->mode ? launch_vx<13, 1>(e, dim3(grid), s, kp) : launch_vx<13, 0>(e, dim3(grid), s, kp); break;
                 default: e->mode ? launch_vx<16, 1>(e, dim3(grid), s, kp) : launch_vx<16, 0>(e, dim3(grid), s, kp); break;
             }
@@ -1210,9 +1221,22 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             bp.remove_dc = kp.remove_dc; bp.fb_power = kp.fb_power; bp.fb_inld = kp.fb_inld; bp.band_log = kp.band_log;
             bp.band_to_scratch = kp.band_to_scratch; bp.lp_is_lpa = kp.lp_is_lpa; bp.lporder = kp.lporder; bp.ncep = kp.ncep;
             bp.lifter_on = kp.lifter_on; bp.preem = kp.preem;
-            const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8;
-            const int g = std::max(1, std::min(pl->n_tiles, e->n_cu * 8));
-            hipLaunchKernelGGL(bigfft_kernel, dim3(g), dim3(256), shm, s, bp);
+            bp.fb_total = e->big_fb_total;
+            const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8 + (size_t)d.wfft / 2 * 8 +
+                               (size_t)((d.window + 3) & ~3) * 4 + (size_t)((e->big_fb_total + 3) & ~3) * 4 +
+                               (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
+                               (size_t)(((e->feat == FEAT_DCTC ? e->ncoef_out * d.B : 0) + 3) & ~3) * 4 + (size_t)((3 * d.B + 3) & ~3) * 4 + 64 * 4;
+            if (shm > 160 * 1024) throw std::runtime_error("filter bank too wide for the LDS tables of the large-FFT kernel");
+            const void *kfn = d.wfft == 1024 ? (const void *)bigfft_kernel<4> : d.wfft == 2048 ? (const void *)bigfft_kernel<8> : (const void *)bigfft_kernel<16>;
+            if (shm > 64 * 1024 && !e->attr_done.count(kfn)) {
+                HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                e->attr_done.insert(kfn);
+            }
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shm));
+            const int g = std::max(1, std::min(pl->n_tiles, e->n_cu * per_cu));
+            if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);
+            else if (d.wfft == 2048) hipLaunchKernelGGL(bigfft_kernel<8>, dim3(g), dim3(256), shm, s, bp);
+            else hipLaunchKernelGGL(bigfft_kernel<16>, dim3(g), dim3(256), shm, s, bp);
         }
         else if (!e->ss) launch();
         else {

@@ -40,7 +40,8 @@ namespace {
 //         and a code path out of the common instantiation.
 // GEN:    GEN_PLAIN = the plain chain (DC removal on, power spectrum, no -fea_E, no exten, no intensity-loudness law,
 //         no diagnostics): the option flags below become constants, which frees 30 SGPRs and the last spills.
-//         GEN_INLD / GEN_EXTEN = the plain chain plus exactly that option (PLP; C4's noise reduction); GEN_FULL reads
+//         GEN_INLD / GEN_EXTEN = the plain chain plus exactly that option (PLP; C4's noise reduction); GEN_DC1 = GEN_FULL
+//         with -remove_dc1; GEN_FULL reads
 //         every flag at run time.
 // LPO:    LP order = number of cepstra when it is fixed at compile time (12: the PLP preset), 0 = run-time orders up to
 //         MAX_LP.  The unrolled Levinson / a->c tail then has no guards and no dead orders.
@@ -62,16 +63,16 @@ namespace {
 //         the overlap-add kernel; no spectra through HBM, no phase 2.
 template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false, bool SY = false>
 __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
-    constexpr bool FULL = GEN == GEN_FULL;
+    constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
     static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
     static_assert(!VF || (MODE == 1 && !VX), "VF: 256-point mode, no spectrum export");
     static_assert(!SS || (MODE == 1 && !VX && !VF && GEN == GEN_PLAIN), "SS: 256-point mode, plain chain");
-    static_assert(!SY || (!VX && !VF && !SS && GEN == GEN_FULL), "SY: run-time flags, no export");
+    static_assert(!SY || (!VX && !VF && !SS && (GEN == GEN_FULL || GEN == GEN_DC1)), "SY: run-time flags, no export");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
     const bool o_skip_phase2 = SY ? true : (FULL ? p.skip_phase2 != 0 : false);
-    const bool o_dc1 = FULL ? p.remove_dc1 != 0 : false;  // -remove_dc1 (decode_kernels.h): run-time flags only
+    constexpr bool o_dc1 = GEN == GEN_DC1;  // -remove_dc1 (decode_kernels.h): an instantiation of its own (generic row count, no export)
     const bool per_wave = (GEN == GEN_EXTEN || FULL || VF || SS) ? p.per_wave != 0 : false;
     extern __shared__ __align__(16) float lds[];
     float *Pt = lds;                       // [TILE][PSTRIDE]

@@ -10,7 +10,7 @@ constexpr int NWAVE = WG / 64;
 constexpr int PSTRIDE = 260;   // floats per P-tile row: 257 bins padded so rows stay 16-byte aligned (b128 reads in phase 2)
 constexpr int LDS_2WG = 80 * 1024;  // two workgroups per CU fit when a workgroup's LDS stays at or under this
 constexpr int MAX_LP = 16;     // Levinson order limit of the in-register recursion
-constexpr int GEN_PLAIN = 0, GEN_INLD = 1, GEN_EXTEN = 2, GEN_FULL = 3;  // front-end option specialisations (frontend_kernel.h)
+constexpr int GEN_PLAIN = 0, GEN_INLD = 1, GEN_EXTEN = 2, GEN_FULL = 3, GEN_DC1 = 4;  // front-end option specialisations (frontend_kernel.h)
 constexpr int MAXC = 24;       // most coefficients accumulated per frame in phase 2 (cepstra incl. c0, or LP lags)
 constexpr int PCM_ALIGN = 8;   // utterance starts are multiples of this many samples
 constexpr int PCM_HEAD = 8;    // samples of padding before the first utterance (x[-2..-1] of frame 0 is loaded)
