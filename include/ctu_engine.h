@@ -103,9 +103,11 @@ int ctu_engine_run(ctu_engine *, const ctu_plan *, const int16_t *d_pcm, float *
 void *ctu_host_alloc(size_t bytes);
 void ctu_host_free(void *);
 
-/* Host-buffer convenience: H2D, run, D2H, synchronised on return.  The device copies are kept in the plan.  rows_per_utt (optional, n_utt
- * entries) receives the number of rows actually produced per utterance (< frames only with
- * -vad_apply_mode drop). */
+/* Host-buffer convenience: H2D, run, D2H, synchronised on return.  The device copies are kept in the plan.  Batches of at
+ * least 16 utterances and 32 MiB in page-locked buffers go in eight utterance ranges on two streams, so the upload of a
+ * range overlaps the kernels and the download of the previous one (environment CTU_HOST_CHUNKS=<n> overrides, 1 = one
+ * range; the hwss / fwss / 2fwss chain always runs in one).  rows_per_utt (optional, n_utt entries) receives the number
+ * of rows actually produced per utterance (< frames only with -vad_apply_mode drop). */
 int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
                         int64_t *rows_per_utt);
 
