@@ -91,6 +91,8 @@ struct ctu_engine {
     int nz = 16;
     int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
     DevBuf<float> lanec, ftab, trapG;
+    DevBuf<uint4> trapG16;   // TRAP on the bf16 matrix pipe: A fragments [8 phases][4 k-steps][3 terms][64 lanes] (trap_kernel.h)
+    bool trap_bf16 = false;
     DevBuf<int> itab;
     // FFT sizes of 1024 to 4096 points (bigfft_kernel.h)
     bool big = false;
@@ -160,8 +162,8 @@ struct ctu_plan {
     DevBuf<long long> d_sample_off;
     // TRAP
     DevBuf<int4> utt_info;
-    DevBuf<int> trap_chunks;
-    int n_trap_chunks = 0;
+    DevBuf<int> trap_chunks, trap_chunks128;   // (utterance, first frame) of every 64- / 128-frame chunk
+    int n_trap_chunks = 0, n_trap_chunks128 = 0;
 };
 
 namespace {
@@ -521,6 +523,54 @@ double check_phase2(const ctu::Design &d, const Phase2Tables &t) {
     return worst;
 }
 
+#ifndef CTU_TRAP_BF16
+#define CTU_TRAP_BF16 1  // 0: TRAP-DCT on the fp32 matrix pipe only (trapdct_mfma_kernel)
+#endif
+// A operands of trapdct_bf16_kernel: G shifted by the frame phase c, zero-padded to 128 taps, each value split into three
+// bf16 terms (round to nearest even at every step, as the device splits the data)
+void build_trap_bf16(ctu_engine *e) {
+    const ctu::Design &d = *e->design;
+    const int tl = d.o.fea_trapdct_traplen, nd = d.o.fea_trapdct_ndct, half = (tl - 1) / 2;
+    e->trap_bf16 = CTU_TRAP_BF16 && nd <= 16 && half <= TB_OFF && 7 + (TB_OFF - half) + tl <= 128 && d.B <= 24;  // 24 bands: 62 KB of LDS (tile 38 KB + two fragment buffers 24 KB): two workgroups per CU
+    if (!e->trap_bf16) return;
+    auto rn = [](float v) {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto up = [](uint16_t h) {
+        uint32_t u = (uint32_t)h << 16;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    std::vector<uint4> tab((size_t)8 * 4 * 3 * 64);
+    for (int c = 0; c < 8; c++)
+        for (int s_ = 0; s_ < 4; s_++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int m = lane & 15, q = lane >> 4;
+                uint16_t term[3][8];
+                for (int i = 0; i < 8; i++) {
+                    const int j = 32 * s_ + 8 * q + i - c - (TB_OFF - half);
+                    const float v = (m < nd && j >= 0 && j < tl) ? (float)d.trap[(size_t)m * tl + j] : 0.f;
+                    term[0][i] = rn(v);
+                    const float r1 = v - up(term[0][i]);
+                    term[1][i] = rn(r1);
+                    term[2][i] = rn(r1 - up(term[1][i]));
+                }
+                for (int sp = 0; sp < 3; sp++) {
+                    uint4 w;
+                    w.x = term[sp][0] | ((uint32_t)term[sp][1] << 16);
+                    w.y = term[sp][2] | ((uint32_t)term[sp][3] << 16);
+                    w.z = term[sp][4] | ((uint32_t)term[sp][5] << 16);
+                    w.w = term[sp][6] | ((uint32_t)term[sp][7] << 16);
+                    tab[(((size_t)c * 4 + s_) * 3 + sp) * 64 + lane] = w;
+                }
+            }
+    e->trapG16.upload(tab);
+}
+
 void build_big_tables(ctu_engine *e) {
     const ctu::Design &d = *e->design;
     const double pi = 3.14159265358979323846;
@@ -586,6 +636,7 @@ void build_big_tables(ctu_engine *e) {
     if (d.kind == ctu::FeaKind::TrapDct) {
         std::vector<float> g(d.trap.begin(), d.trap.end());
         e->trapG.upload(g);
+        build_trap_bf16(e);
     }
     switch (d.kind) {
         case ctu::FeaKind::Dctc: e->feat = FEAT_DCTC; break;
@@ -661,6 +712,7 @@ void build_tables(ctu_engine *e) {
     if (d.kind == ctu::FeaKind::TrapDct) {
         std::vector<float> g(d.trap.begin(), d.trap.end());
         e->trapG.upload(g);
+        build_trap_bf16(e);
     }
     switch (d.kind) {
         case ctu::FeaKind::Spec:
@@ -1082,6 +1134,15 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             pl->utt_info.upload(uinfo);
             pl->trap_chunks.upload(chunks);
             pl->n_trap_chunks = (int)chunks.size() / 2;
+            std::vector<int> c128;
+            for (size_t k = 0; k + 1 < chunks.size(); k += 2)
+                if (!(chunks[k + 1] & 64)) {
+                    c128.push_back(chunks[k]);
+                    c128.push_back(chunks[k + 1]);
+                }
+            pl->n_trap_chunks128 = (int)c128.size() / 2;
+            if (c128.empty()) c128.assign(2, 0);
+            pl->trap_chunks128.upload(c128);
         }
         if (d.kind == ctu::FeaKind::TrapDct) pl->logmel.alloc((size_t)ro * d.B);
         if (d.post_order > 0 || d.cms) pl->base_rows.alloc((size_t)ro * d.Dbase);
@@ -1316,7 +1377,16 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
 #define TRAP_LAUNCH(NRB, NSM)                                                                                          \
     hipLaunchKernelGGL((trapdct_mfma_kernel<NRB, NSM>), dim3(pl->n_trap_chunks), dim3(256), shm, s, pl->logmel.p, d_rows, \
                        e->trapG.p, pl->utt_info.p, pl->trap_chunks.p, d.B, tl, nd, d.D)
-            if (nd <= 16 && ns <= 26) TRAP_LAUNCH(1, 26);
+            if (e->trap_bf16) {
+                const size_t shm16 = (size_t)3 * d.B * TB_TT * 2 + (size_t)((d.B + 3) & ~3) * 4 + 2 * 768 * 16;
+                if (shm16 > 64 * 1024 && !e->attr_done.count((const void *)trapdct_bf16_kernel)) {
+                    HIP_TRY(hipFuncSetAttribute((const void *)trapdct_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    e->attr_done.insert((const void *)trapdct_bf16_kernel);
+                }
+                hipLaunchKernelGGL(trapdct_bf16_kernel, dim3(std::max(pl->n_trap_chunks128, 1)), dim3(256), shm16, s, pl->logmel.p, d_rows,
+                                   e->trapG16.p, pl->utt_info.p, pl->trap_chunks128.p, pl->n_trap_chunks128, d.B, nd, d.D);
+            }
+            else if (nd <= 16 && ns <= 26) TRAP_LAUNCH(1, 26);
             else if (nd <= 16) TRAP_LAUNCH(1, 64);
             else if (ns <= 26) TRAP_LAUNCH(2, 26);
             else TRAP_LAUNCH(2, 64);

@@ -73,4 +73,156 @@ __global__ __launch_bounds__(256) void trapdct_mfma_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same contraction on the bf16 matrix pipe with fp32 accuracy: every operand is split into three bf16 terms
+// (x = h + m + l exactly to 2^-24) and the six products hh, hm, mh, hl, lh, mm accumulate in fp32 - what is dropped
+// (ml, lm, ll) is 2^-24 relative.  v_mfma_f32_16x16x32_bf16 does 8x the multiply-adds of the fp32 form per cycle, so six
+// of them are 2.2x faster than the fp32 kernel above where that one is bound (65 % of the fp32 matrix peak).
+// The Toeplitz operand X[j][t] = x[t + j - half] wants 8 consecutive taps per lane (16-byte LDS reads), i.e. a start that
+// is a multiple of 8 for every column: the 16 columns of an MFMA are therefore output frames 8 apart (t = tc + 8 n + c),
+// and each of the 8 phases c has its own copy of G shifted by c taps (host table, zero-padded to K = 128):
+//     D[k][n] = sum_j' Gc[k][j'] X[8 n + j'],   X[tau] = x(tc - OFF + tau) - x0(band),   j' = j + c + OFF - half
+// (rows of G sum to zero, so the per-band constant x0 - the tile's centre value - drops out and keeps the split small).
+// One workgroup = 128 output frames x all bands; wave w takes bands w, w+4, ...; A fragments of a phase (4 k-steps x 3
+// terms) live in 48 VGPRs while the wave walks its bands.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int TB_TT = 264;   // tile row in frames: 8 * 15 + 127 < 256 used; 528 bytes per row spreads the bands over the banks and keeps 16-byte alignment
+constexpr int TB_OFF = 56;   // tile origin tc - 56: a multiple of 8 not below half = 50
+
+// Workgroup barrier for LDS hand-overs only: __syncthreads() also drains the vector-memory counter, which would put the
+// latency of a phase's row stores in front of the next phase.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ unsigned bf16_rn(float v) {  // round to nearest even, finite inputs
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
+                                                           const uint4 *__restrict__ Gtab, const int4 *__restrict__ utt_info,
+                                                           const int *__restrict__ chunk_tab, int n_chunks, int B, int ndct, int D) {
+    extern __shared__ __align__(16) unsigned short xt[];  // [3][B][TB_TT] bf16 terms, then x0[B] floats
+    if ((int)blockIdx.x >= n_chunks) return;
+    const int u = chunk_tab[blockIdx.x * 2], tc = chunk_tab[blockIdx.x * 2 + 1];  // chunks of 128 frames
+    const int4 ui = utt_info[u];
+    const int64_t r0 = ((int64_t)ui.y << 32) | (uint32_t)ui.x;
+    const int T = ui.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *x0 = reinterpret_cast<float *>(xt + 3 * B * TB_TT);
+    if (tid < B) {
+        int t = tc + 64;
+        t = t > T - 1 ? T - 1 : t;
+        x0[tid] = logmel[(r0 + t) * B + tid];
+    }
+    __syncthreads();
+    // log-mel tile with the first / last frame replicated beyond the utterance (src/fea/fea_trap.cc:64-70,111-127)
+    unsigned *xt32 = reinterpret_cast<unsigned *>(xt);
+    {
+        // two frames per lane and step (one dword store per term); every load of the tile is issued before the first use
+        constexpr int NF = 12;  // ceil(128 * 24 / 256): B <= 24 on this path
+        float v0[NF], v1[NF];
+#pragma unroll
+        for (int it = 0; it < NF; it++) {
+            const int e = min(tid + 256 * it, 128 * B - 1);  // unconditional loads (a branch per step would serialise them)
+            const int pr = e / B, b = e - pr * B;
+            int t0_ = tc - TB_OFF + 2 * pr, t1_ = t0_ + 1;
+            t0_ = t0_ < 0 ? 0 : (t0_ > T - 1 ? T - 1 : t0_);
+            t1_ = t1_ < 0 ? 0 : (t1_ > T - 1 ? T - 1 : t1_);
+            v0[it] = logmel[(r0 + t0_) * B + b];
+            v1[it] = logmel[(r0 + t1_) * B + b];
+        }
+#pragma unroll
+        for (int it = 0; it < NF; it++) {
+            const int e = tid + 256 * it;
+            if (e < 128 * B) {
+                const int pr = e / B, b = e - pr * B;
+                unsigned h2 = 0, m2 = 0, l2 = 0;
+#pragma unroll
+                for (int z = 0; z < 2; z++) {
+                    const float v = (z ? v1[it] : v0[it]) - x0[b];
+                    const unsigned h = bf16_rn(v);
+                    const float r1 = v - __uint_as_float(h << 16);
+                    const unsigned m = bf16_rn(r1);
+                    const unsigned l = bf16_rn(r1 - __uint_as_float(m << 16));
+                    h2 |= h << (16 * z);
+                    m2 |= m << (16 * z);
+                    l2 |= l << (16 * z);
+                }
+                xt32[((0 * B + b) * TB_TT >> 1) + pr] = h2;
+                xt32[((1 * B + b) * TB_TT >> 1) + pr] = m2;
+                xt32[((2 * B + b) * TB_TT >> 1) + pr] = l2;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = lane & 15, q = lane >> 4;
+    // A fragments of a phase: 12 x 64 lanes x 16 bytes, fetched once per workgroup into LDS one phase ahead (every wave
+    // needs all of them).  One LDS-only barrier per phase: nothing in the loop waits for the rows' stores.
+    uint4 *abuf = reinterpret_cast<uint4 *>(x0 + ((B + 3) & ~3));  // [2][768]
+#pragma unroll
+    for (int z = 0; z < 3; z++) abuf[tid + 256 * z] = Gtab[tid + 256 * z];
+    for (int c = 0; c < 8; c++) {
+        lds_barrier();  // phase c's fragments are in abuf[c & 1]; every wave is done with the other half
+        // next phase's fragments: three named registers, fetched unconditionally (the last phase re-reads its own): an
+        // array defined under a condition went to scratch, with a full vmcnt drain behind every one of its loads
+        const uint4 *gn = Gtab + (c + 1 < 8 ? c + 1 : c) * 768 + tid;
+        const uint4 pre0 = gn[0], pre1 = gn[256], pre2 = gn[512];
+        bf16x8 a[4][3];
+        const uint4 *ab = abuf + (c & 1) * 768;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; s_++)
+#pragma unroll
+            for (int sp = 0; sp < 3; sp++) a[s_][sp] = __builtin_bit_cast(bf16x8, ab[(s_ * 3 + sp) * 64 + lane]);
+        const int t_out = tc + 8 * n + c;
+        // the wave's bands two at a time: the tile fragments of the next band are on their way while this band's 24 MFMAs run
+        auto load_x = [&](bf16x8 (&X)[4][3], int b) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) {
+                const int tau = 8 * n + 32 * s_ + 8 * q;
+#pragma unroll
+                for (int sp = 0; sp < 3; sp++) X[s_][sp] = *reinterpret_cast<const bf16x8 *>(xt + (sp * B + b) * TB_TT + tau);
+            }
+        };
+        auto compute = [&](const bf16x8 (&X)[4][3], int b) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) {
+                // smallest terms first (one accumulation chain: four interleaved chains measured the same)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][1], X[s_][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][2], X[s_][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0], X[s_][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][1], X[s_][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0], X[s_][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0], X[s_][0], acc, 0, 0, 0);
+            }
+            if (t_out < T) {
+                if (ndct == 16 && (D & 3) == 0) {
+                    // C/D layout: this lane holds coefficients 4*(lane>>4)..+3 of frame column lane&15: one 16-byte store
+                    *reinterpret_cast<f32x4 *>(rows + (r0 + t_out) * D + b * 16 + q * 4) = acc;
+                } else {
+                    float *o = rows + (r0 + t_out) * D + b * ndct;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (q * 4 + r < ndct) o[q * 4 + r] = acc[r];
+                }
+            }
+        };
+        bf16x8 X0[4][3], X1[4][3];
+        if (wave < B) load_x(X0, wave);
+        for (int b = wave; b < B; b += 8) {
+            if (b + 4 < B) load_x(X1, b + 4);
+            compute(X0, b);
+            if (b + 4 < B) {
+                if (b + 8 < B) load_x(X0, b + 8);
+                compute(X1, b + 4);
+            }
+        }
+        uint4 *an = abuf + ((c + 1) & 1) * 768 + tid;
+        an[0] = pre0;
+        an[256] = pre1;
+        an[512] = pre2;
+    }
+}
+
 }  // namespace
