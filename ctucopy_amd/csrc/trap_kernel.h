@@ -160,9 +160,18 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
     // A fragments of a phase: 12 x 64 lanes x 16 bytes, fetched once per workgroup into LDS one phase ahead (every wave
     // needs all of them).  One LDS-only barrier per phase: nothing in the loop waits for the rows' stores.
     uint4 *abuf = reinterpret_cast<uint4 *>(x0 + ((B + 3) & ~3));  // [2][768]
+#ifndef TB_DIRECT_A
 #pragma unroll
     for (int z = 0; z < 3; z++) abuf[tid + 256 * z] = Gtab[tid + 256 * z];
+#endif
     for (int c = 0; c < 8; c++) {
+#ifdef TB_DIRECT_A  // experiment: fragments straight from L2, no barrier in the loop
+        bf16x8 a[4][3];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; s_++)
+#pragma unroll
+            for (int sp = 0; sp < 3; sp++) a[s_][sp] = __builtin_bit_cast(bf16x8, Gtab[((c * 4 + s_) * 3 + sp) * 64 + lane]);
+#else
         lds_barrier();  // phase c's fragments are in abuf[c & 1]; every wave is done with the other half
         // next phase's fragments: three named registers, fetched unconditionally (the last phase re-reads its own): an
         // array defined under a condition went to scratch, with a full vmcnt drain behind every one of its loads
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
         for (int s_ = 0; s_ < 4; s_++)
 #pragma unroll
             for (int sp = 0; sp < 3; sp++) a[s_][sp] = __builtin_bit_cast(bf16x8, ab[(s_ * 3 + sp) * 64 + lane]);
+#endif
         const int t_out = tc + 8 * n + c;
         // the wave's bands two at a time: the tile fragments of the next band are on their way while this band's 24 MFMAs run
         auto load_x = [&](bf16x8 (&X)[4][3], int b) {
@@ -218,10 +228,12 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
                 compute(X1, b + 4);
             }
         }
+#ifndef TB_DIRECT_A
         uint4 *an = abuf + ((c + 1) & 1) * 768 + tid;
         an[0] = pre0;
         an[256] = pre1;
         an[512] = pre2;
+#endif
     }
 }
 
