@@ -293,8 +293,10 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     for (int j = 0; j < NZ; j++) {
                         const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];
                         const float w = (j & 1) ? w4.z : w4.x;  // 0 beyond the window
-                        float pa = (float)xa[16 * j - 1], pb = (float)xb[16 * j - 1];
-                        float a0 = (float)xa[16 * j], b0 = (float)xb[16 * j];
+                        // x[i-1] and x[i] in one 2-byte-aligned dword load (global memory takes unaligned dwords)
+                        const uint32_t wa = reinterpret_cast<const pcm2 *>(xa + 16 * j - 1)->v, wb = reinterpret_cast<const pcm2 *>(xb + 16 * j - 1)->v;
+                        float pa = (float)(int16_t)(wa & 0xffffu), pb = (float)(int16_t)(wb & 0xffffu);
+                        float a0 = (float)(int16_t)(wa >> 16), b0 = (float)(int16_t)(wb >> 16);
                         if (o_dc1) {
                             const int i = 16 * j + l16;
                             pa -= dc1_cum(ova, i - 1, i >= 1);

@@ -281,6 +281,9 @@ __device__ __forceinline__ double lanes8_allreduce_add(double x) {
 }
 
 
+struct __attribute__((packed, aligned(2))) pcm2 {  // two consecutive int16 samples at any sample address
+    uint32_t v;
+};
 struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-byte aligned
     uint32_t lo, hi;
 };
