@@ -1383,7 +1383,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                     HIP_TRY(hipFuncSetAttribute((const void *)trapdct_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     e->attr_done.insert((const void *)trapdct_bf16_kernel);
                 }
-                hipLaunchKernelGGL(trapdct_bf16_kernel, dim3(std::max(pl->n_trap_chunks128, 1)), dim3(256), shm16, s, pl->logmel.p, d_rows,
+                hipLaunchKernelGGL(trapdct_bf16_kernel, dim3(std::max(pl->n_trap_chunks128, 1)), dim3(512), shm16, s, pl->logmel.p, d_rows,
                                    e->trapG16.p, pl->utt_info.p, pl->trap_chunks128.p, pl->n_trap_chunks128, d.B, nd, d.D);
             }
             else if (nd <= 16 && ns <= 26) TRAP_LAUNCH(1, 26);

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void trapdct_mfma_kernel(const float *__restri
 // and each of the 8 phases c has its own copy of G shifted by c taps (host table, zero-padded to K = 128):
 //     D[k][n] = sum_j' Gc[k][j'] X[8 n + j'],   X[tau] = x(tc - OFF + tau) - x0(band),   j' = j + c + OFF - half
 // (rows of G sum to zero, so the per-band constant x0 - the tile's centre value - drops out and keeps the split small).
-// One workgroup = 128 output frames x all bands; wave w takes bands w, w+4, ...; A fragments of a phase (4 k-steps x 3
-// terms) live in 48 VGPRs while the wave walks its bands.
+// One workgroup (8 waves, at most 128 VGPRs: two workgroups = four waves per SIMD on a CU) = 128 output frames x all
+// bands; wave w takes bands w, w+8, ...; A fragments of a phase (4 k-steps x 3 terms) live in 48 VGPRs meanwhile.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int TB_TT = 264;   // tile row in frames: 8 * 15 + 127 < 256 used; 528 bytes per row spreads the bands over the banks and keeps 16-byte alignment
 constexpr int TB_OFF = 56;   // tile origin tc - 56: a multiple of 8 not below half = 50
@@ -99,7 +99,7 @@ __device__ __forceinline__ unsigned bf16_rn(float v) {  // round to nearest even
     return u >> 16;
 }
 
-__global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
+__global__ __launch_bounds__(512, 2) void trapdct_bf16_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
                                                            const uint4 *__restrict__ Gtab, const int4 *__restrict__ utt_info,
                                                            const int *__restrict__ chunk_tab, int n_chunks, int B, int ndct, int D) {
     extern __shared__ __align__(16) unsigned short xt[];  // [3][B][TB_TT] bf16 terms, then x0[B] floats
@@ -120,11 +120,11 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
     unsigned *xt32 = reinterpret_cast<unsigned *>(xt);
     {
         // two frames per lane and step (one dword store per term); every load of the tile is issued before the first use
-        constexpr int NF = 12;  // ceil(128 * 24 / 256): B <= 24 on this path
+        constexpr int NF = 6;  // ceil(128 * 24 / 512): B <= 24 on this path
         float v0[NF], v1[NF];
 #pragma unroll
         for (int it = 0; it < NF; it++) {
-            const int e = min(tid + 256 * it, 128 * B - 1);  // unconditional loads (a branch per step would serialise them)
+            const int e = min(tid + 512 * it, 128 * B - 1);  // unconditional loads (a branch per step would serialise them)
             const int pr = e / B, b = e - pr * B;
             int t0_ = tc - TB_OFF + 2 * pr, t1_ = t0_ + 1;
             t0_ = t0_ < 0 ? 0 : (t0_ > T - 1 ? T - 1 : t0_);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
         }
 #pragma unroll
         for (int it = 0; it < NF; it++) {
-            const int e = tid + 256 * it;
+            const int e = tid + 512 * it;
             if (e < 128 * B) {
                 const int pr = e / B, b = e - pr * B;
                 unsigned h2 = 0, m2 = 0, l2 = 0;
@@ -160,32 +160,22 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
     // A fragments of a phase: 12 x 64 lanes x 16 bytes, fetched once per workgroup into LDS one phase ahead (every wave
     // needs all of them).  One LDS-only barrier per phase: nothing in the loop waits for the rows' stores.
     uint4 *abuf = reinterpret_cast<uint4 *>(x0 + ((B + 3) & ~3));  // [2][768]
-#ifndef TB_DIRECT_A
-#pragma unroll
-    for (int z = 0; z < 3; z++) abuf[tid + 256 * z] = Gtab[tid + 256 * z];
-#endif
+    abuf[tid] = Gtab[tid];
+    if (tid < 256) abuf[tid + 512] = Gtab[tid + 512];
     for (int c = 0; c < 8; c++) {
-#ifdef TB_DIRECT_A  // experiment: fragments straight from L2, no barrier in the loop
-        bf16x8 a[4][3];
-#pragma unroll
-        for (int s_ = 0; s_ < 4; s_++)
-#pragma unroll
-            for (int sp = 0; sp < 3; sp++) a[s_][sp] = __builtin_bit_cast(bf16x8, Gtab[((c * 4 + s_) * 3 + sp) * 64 + lane]);
-#else
         lds_barrier();  // phase c's fragments are in abuf[c & 1]; every wave is done with the other half
-        // next phase's fragments: three named registers, fetched unconditionally (the last phase re-reads its own): an
-        // array defined under a condition went to scratch, with a full vmcnt drain behind every one of its loads
-        const uint4 *gn = Gtab + (c + 1 < 8 ? c + 1 : c) * 768 + tid;
-        const uint4 pre0 = gn[0], pre1 = gn[256], pre2 = gn[512];
+        // next phase's fragments: named registers, fetched unconditionally (the last phase re-reads its own; the upper
+        // half of the workgroup re-reads an entry of the lower half): an array defined under a condition went to scratch
+        const uint4 *gn = Gtab + (c + 1 < 8 ? c + 1 : c) * 768;
+        const uint4 pre0 = gn[tid], pre1 = gn[512 + (tid & 255)];
         bf16x8 a[4][3];
         const uint4 *ab = abuf + (c & 1) * 768;
 #pragma unroll
         for (int s_ = 0; s_ < 4; s_++)
 #pragma unroll
             for (int sp = 0; sp < 3; sp++) a[s_][sp] = __builtin_bit_cast(bf16x8, ab[(s_ * 3 + sp) * 64 + lane]);
-#endif
         const int t_out = tc + 8 * n + c;
-        // the wave's bands two at a time: the tile fragments of the next band are on their way while this band's 24 MFMAs run
+        // a band of the wave: 12 tile fragments from LDS, 24 MFMAs, one row store
         auto load_x = [&](bf16x8 (&X)[4][3], int b) {
 #pragma unroll
             for (int s_ = 0; s_ < 4; s_++) {
@@ -218,22 +208,15 @@ __global__ __launch_bounds__(256) void trapdct_bf16_kernel(const float *__restri
                 }
             }
         };
-        bf16x8 X0[4][3], X1[4][3];
-        if (wave < B) load_x(X0, wave);
+        // eight waves share the tile and the fragments; four waves per SIMD cover each other's LDS round trips
         for (int b = wave; b < B; b += 8) {
-            if (b + 4 < B) load_x(X1, b + 4);
+            bf16x8 X0[4][3];
+            load_x(X0, b);
             compute(X0, b);
-            if (b + 4 < B) {
-                if (b + 8 < B) load_x(X0, b + 8);
-                compute(X1, b + 4);
-            }
         }
-#ifndef TB_DIRECT_A
-        uint4 *an = abuf + ((c + 1) & 1) * 768 + tid;
-        an[0] = pre0;
-        an[256] = pre1;
-        an[512] = pre2;
-#endif
+        uint4 *an = abuf + ((c + 1) & 1) * 768;
+        an[tid] = pre0;
+        if (tid < 256) an[512 + tid] = pre1;
     }
 }
 
