@@ -526,6 +526,9 @@ double check_phase2(const ctu::Design &d, const Phase2Tables &t) {
 #ifndef CTU_TRAP_BF16
 #define CTU_TRAP_BF16 1  // 0: TRAP-DCT on the fp32 matrix pipe only (trapdct_mfma_kernel)
 #endif
+#ifndef CTU_TRAP_F16
+#define CTU_TRAP_F16 1   // 1: two fp16 terms, three products; 0: three bf16 terms, six products (trap_kernel.h)
+#endif
 // A operands of trapdct_bf16_kernel: G shifted by the frame phase c, zero-padded to 128 taps, each value split into three
 // bf16 terms (round to nearest even at every step, as the device splits the data)
 void build_trap_bf16(ctu_engine *e) {
@@ -545,7 +548,9 @@ void build_trap_bf16(ctu_engine *e) {
         std::memcpy(&f, &u, 4);
         return f;
     };
-    std::vector<uint4> tab((size_t)8 * 4 * 3 * 64);
+    const bool f16 = CTU_TRAP_F16;
+    const int NT = f16 ? 2 : 3;
+    std::vector<uint4> tab((size_t)8 * 4 * NT * 64);
     for (int c = 0; c < 8; c++)
         for (int s_ = 0; s_ < 4; s_++)
             for (int lane = 0; lane < 64; lane++) {
@@ -554,18 +559,25 @@ void build_trap_bf16(ctu_engine *e) {
                 for (int i = 0; i < 8; i++) {
                     const int j = 32 * s_ + 8 * q + i - c - (TB_OFF - half);
                     const float v = (m < nd && j >= 0 && j < tl) ? (float)d.trap[(size_t)m * tl + j] : 0.f;
-                    term[0][i] = rn(v);
-                    const float r1 = v - up(term[0][i]);
-                    term[1][i] = rn(r1);
-                    term[2][i] = rn(r1 - up(term[1][i]));
+                    if (f16) {
+                        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+                        std::memcpy(&term[0][i], &h, 2);
+                        std::memcpy(&term[1][i], &l, 2);
+                        term[2][i] = 0;
+                    } else {
+                        term[0][i] = rn(v);
+                        const float r1 = v - up(term[0][i]);
+                        term[1][i] = rn(r1);
+                        term[2][i] = rn(r1 - up(term[1][i]));
+                    }
                 }
-                for (int sp = 0; sp < 3; sp++) {
+                for (int sp = 0; sp < NT; sp++) {
                     uint4 w;
                     w.x = term[sp][0] | ((uint32_t)term[sp][1] << 16);
                     w.y = term[sp][2] | ((uint32_t)term[sp][3] << 16);
                     w.z = term[sp][4] | ((uint32_t)term[sp][5] << 16);
                     w.w = term[sp][6] | ((uint32_t)term[sp][7] << 16);
-                    tab[(((size_t)c * 4 + s_) * 3 + sp) * 64 + lane] = w;
+                    tab[(((size_t)c * 4 + s_) * NT + sp) * 64 + lane] = w;
                 }
             }
     e->trapG16.upload(tab);
@@ -1378,13 +1390,10 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
     hipLaunchKernelGGL((trapdct_mfma_kernel<NRB, NSM>), dim3(pl->n_trap_chunks), dim3(256), shm, s, pl->logmel.p, d_rows, \
                        e->trapG.p, pl->utt_info.p, pl->trap_chunks.p, d.B, tl, nd, d.D)
             if (e->trap_bf16) {
-                const size_t shm16 = (size_t)3 * d.B * TB_TT * 2 + (size_t)((d.B + 3) & ~3) * 4 + 2 * 768 * 16;
-                if (shm16 > 64 * 1024 && !e->attr_done.count((const void *)trapdct_bf16_kernel)) {
-                    HIP_TRY(hipFuncSetAttribute((const void *)trapdct_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    e->attr_done.insert((const void *)trapdct_bf16_kernel);
-                }
-                hipLaunchKernelGGL(trapdct_bf16_kernel, dim3(std::max(pl->n_trap_chunks128, 1)), dim3(512), shm16, s, pl->logmel.p, d_rows,
-                                   e->trapG16.p, pl->utt_info.p, pl->trap_chunks128.p, pl->n_trap_chunks128, d.B, nd, d.D);
+                constexpr int NT16 = CTU_TRAP_F16 ? 2 : 3;
+                const size_t shm16 = (size_t)NT16 * d.B * TB_TT * 2 + (size_t)((d.B + 3) & ~3) * 4 + 2 * (4 * NT16 * 64) * 16;
+                hipLaunchKernelGGL((trapdct_split16_kernel<CTU_TRAP_F16 != 0>), dim3(std::max(pl->n_trap_chunks128, 1)), dim3(512), shm16, s,
+                                   pl->logmel.p, d_rows, e->trapG16.p, pl->utt_info.p, pl->trap_chunks128.p, pl->n_trap_chunks128, d.B, nd, d.D);
             }
             else if (nd <= 16 && ns <= 26) TRAP_LAUNCH(1, 26);
             else if (nd <= 16) TRAP_LAUNCH(1, 64);
