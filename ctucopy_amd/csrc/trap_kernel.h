@@ -123,8 +123,11 @@ __device__ __forceinline__ void split16(float v, unsigned (&t)[3]) {
     }
 }
 
+#ifndef TB_WGS
+#define TB_WGS 2
+#endif
 template <bool F16>
-__global__ __launch_bounds__(512, 2) void trapdct_split16_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
+__global__ __launch_bounds__(512, TB_WGS) void trapdct_split16_kernel(const float *__restrict__ logmel, float *__restrict__ rows,
                                                                 const uint4 *__restrict__ Gtab, const int4 *__restrict__ utt_info,
                                                                 const int *__restrict__ chunk_tab, int n_chunks, int B, int ndct, int D) {
     constexpr int NT = F16 ? 2 : 3;       // terms per operand
