@@ -500,6 +500,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // every lane has its gains before the scratch (P rows 4-7) is reused
             vf_inverse_fft(vn, ltw4, (uint32_t)(size_t)(lvoid_t *)scratch, scratch + 65 * l16 + 16 * fg);
+            STAMP(11);  // VF / SS: spectra re-scaled, inverse transform
             // time-domain frames into the wave's LDS rows (the spectra are spent): frame slot s at s * VF_FSTRIDE
             float *ta = Pw + (2 * fg) * VF_FSTRIDE + l16, *tb = ta + VF_FSTRIDE;
 #pragma unroll
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            STAMP(12);  // VF / SS: frames re-laid, Burg lattice, cepstra
         };
 
         // ================= hwss / fwss / 2fwss (src/nr/nr.cc:181-442) =================
@@ -1033,6 +1035,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                     vad_frame(vrun, p.vad, rec.t0 + slot0 + s_, 0.0, cil, lane, vout);
                 }
                 if (rec.t0 + slot0 + nv == rec.T) vad_flush(vrun, p.vad, rec.T, lane, vout);
+                STAMP(13);  // VF: decision replay of the step's frames
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

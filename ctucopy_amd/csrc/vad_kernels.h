@@ -284,17 +284,18 @@ __device__ __forceinline__ void vad_frame(VadRun &r, const VadParams &vp, int t,
         r.c0r = vp.cep_p * r.c0r + (1.0 - vp.cep_p) * cil;
     vad_push(r, vad0, order);
     if (t >= h) {
-        if (lane == 0) out[r.nout] = ((double)r.nsum / (double)order >= 0.5) ? '1' : '0';
+        if (lane == 0) out[r.nout] = (2 * r.nsum >= order) ? '1' : '0';
         r.nout++;
     }
 }
 
+// (The majority test (double)nsum / order >= 0.5 of src/vad/vad.h:139-150 is taken as 2 nsum >= order: the same for integers.)
 // End of an utterance of T frames: zeros are pushed until every frame has its byte (src/vad/vad.h:156-175).
 __device__ __forceinline__ void vad_flush(VadRun &r, const VadParams &vp, int T, int lane, uint8_t *out) {
     const int order = vp.filter_order, h = (order - 1) / 2;
     for (int k = 0; k < h && r.nout < T; k++) {
         vad_push(r, 0, order);
-        if (lane == 0) out[r.nout] = ((double)r.nsum / (double)order >= 0.5) ? '1' : '0';
+        if (lane == 0) out[r.nout] = (2 * r.nsum >= order) ? '1' : '0';
         r.nout++;
     }
 }
