@@ -629,11 +629,21 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 }
             }
             const xstate_t pp = (xstate_t)p.nr_p_d, qq = (xstate_t)1.0 - pp;
+            // the next frame's values are read while this frame's recurrence runs (the chain goes through Navg / Yavg in
+            // registers, not through LDS); bins beyond K read the row's padding / the next row: finite, never stored
+            float Xn[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) Xn[j] = Pw[f_lo * PSTRIDE + lane + 64 * j];
             for (int f = f_lo; f < f_hi; f++) {
                 float *row = Pw + f * PSTRIDE + lane;
                 float X[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; j++) X[j] = (lane + 64 * j < p.K) ? row[64 * j] : 1.f;
+                for (int j = 0; j < NJ; j++) X[j] = (lane + 64 * j < p.K) ? Xn[j] : 1.f;
+                {
+                    const float *nrow = Pw + (f + 1 < f_hi ? f + 1 : f) * PSTRIDE + lane;
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) Xn[j] = nrow[64 * j];
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     // H = Navg / (Navg^a + Yavg^a)^(1/a); the output X - H X is formed as X (1 - H) with 1 - H written
