@@ -1037,12 +1037,17 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 // decision replay of the step's frames, in order (vad_kernels.h): lane i takes coefficient i of frame s
                 if (rec.t0 == 0 && slot0 == 0) vad_run_reset(vrun);
                 uint8_t *vout = p.vad_out + (rbase - rec.t0);
+                // the coefficients of the next frame are fetched across the lanes while this frame's decision is worked out
+                float ca = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 15) << 2, __float_as_int(mine_ab[0])));
+                float cb = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 15) << 2, __float_as_int(mine_ab[1])));
                 for (int s_ = 0; s_ < nv; s_++) {
-                    const int src = ((16 * (s_ >> 1) + (lane & 15)) << 2);
-                    const float ca = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mine_ab[0])));
-                    const float cb = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mine_ab[1])));
                     const double cil = lane < VF_NC ? (double)((s_ & 1) ? cb : ca) : 0.0;
+                    const int srcn = ((16 * (((s_ + 1) & 7) >> 1) + (lane & 15)) << 2);
+                    const float nca = __int_as_float(__builtin_amdgcn_ds_bpermute(srcn, __float_as_int(mine_ab[0])));
+                    const float ncb = __int_as_float(__builtin_amdgcn_ds_bpermute(srcn, __float_as_int(mine_ab[1])));
                     vad_frame(vrun, p.vad, rec.t0 + slot0 + s_, 0.0, cil, lane, vout);
+                    ca = nca;
+                    cb = ncb;
                 }
                 if (rec.t0 + slot0 + nv == rec.T) vad_flush(vrun, p.vad, rec.T, lane, vout);
                 STAMP(13);  // VF: decision replay of the step's frames
