@@ -4,6 +4,8 @@
 // FFT as a Stockham radix-2 autosort through two LDS buffers, the power spectrum in LDS, four lanes per band for the
 // filter bank, one lane per output coefficient.  The plain chain only (no noise reduction, no VAD): pre-emphasis,
 // window, mean removal, |.|^2 or |.|, any filter bank, ^0.33, log, DCT / band outputs / LP analysis, the energy column.
+// Every barrier here hands over LDS data only (lds_barrier, trap_kernel.h): __syncthreads() would also drain the vector-memory
+// counter, i.e. wait for the samples fetched a frame ahead and for the previous frame's row stores at every pass.
 // Included by engine.hip.
 #pragma once
 
@@ -30,9 +32,9 @@ struct BigParams {
 
 __device__ __forceinline__ double block_sum(double v, double *red) {  // 256 threads; red: 4 doubles of LDS
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     return red[0] + red[1] + red[2] + red[3];
 }
 
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
     for (int i = tid; i < ncd; i += 256) lcoef_d[i] = p.coef_d[i];
     for (int i = tid; i < ncf; i += 256) lcoef[i] = p.coef[i];
     for (int i = tid; i < 3 * p.B; i += 256) lrange[i] = p.fb_range[i];
-    __syncthreads();
+    lds_barrier();
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const TileRec rec = load_rec(p.tiles, tile);
         // the samples of a frame are fetched one frame ahead (registers): the loads fly under the previous frame's passes
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
             }
             double e_raw = 0.0;
             if (p.e_mode == 4) e_raw = block_sum(raw, red);
-            __syncthreads();
+            lds_barrier();
             // ---- Nc-point complex FFT, Stockham radix-2: log2(Nc) passes between the two buffers
             float2 *src = A, *dst = Bf;
             for (int Ns = 1; Ns < Nc; Ns <<= 1) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                     dst[j0] = make_float2(a.x + b.x, a.y + b.y);
                     dst[j0 + Ns] = make_float2(a.x - b.x, a.y - b.y);
                 }
-                __syncthreads();
+                lds_barrier();
                 float2 *t_ = src;
                 src = dst;
                 dst = t_;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 }
                 P[k] = p.fb_power ? pw : sqrtf(pw);  // src/io/in.cc:415-417
             }
-            __syncthreads();
+            lds_barrier();
             double e_spec = 0.0;
             if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) (src/nr/nr.cc:36-45)
                 double s = 0.0;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                     Ylog[b] = b < p.B ? __builtin_amdgcn_logf(acc) * 0.69314718056f : 0.f;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             const int64_t row = rec.rbase + f;
             double e_band = 0.0;
             if (p.e_mode == 3 && tid == 0) {  // band energy of the FB output (src/fea/fea_impl.cc:44-50,68-74)
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 else if (p.e_mode == 4) e = log(e_raw);
                 p.rows[row * p.D + p.e_slot] = (float)e;
             }
-            __syncthreads();  // P, Y and the FFT buffers are rewritten by the next frame
+            lds_barrier();  // P, Y and the FFT buffers are rewritten by the next frame
         }
     }
 }
