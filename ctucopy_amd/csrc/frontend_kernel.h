@@ -28,6 +28,9 @@ namespace {
 #ifndef CTU_DUAL
 #define CTU_DUAL 1      // the two passes of the 512-point mode side by side in the headline instantiation (see DUAL below)
 #endif
+#ifndef CTU_BURG_UNROLL2
+#define CTU_BURG_UNROLL2 0  // 1: the two lattices of a 16-lane group unrolled into one block (the scheduler may interleave them)
+#endif
 #ifndef CTU_EXTEN_F64
 #define CTU_EXTEN_F64 0 // 1: exten state (Navg, Yavg) and its update in double.  Measured (tools/probes/sweep_err.py, exten_err.py): no accuracy gain - the residual is fp32 FFT noise amplified where a bin is almost fully suppressed - and -30 % throughput
 #endif
@@ -510,6 +513,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#if CTU_BURG_UNROLL2
+#pragma unroll
+#endif
             for (int xb = 0; xb < 2; xb++) {  // frame A, then frame B of this 16-lane group
                 const float *tx = Pw + (2 * fg + xb) * VF_FSTRIDE + VF_SPL * l16;
                 float x[VF_SPL];
