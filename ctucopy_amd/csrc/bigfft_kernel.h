@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
         for (int f = 0; f < rec.nvalid; f++) {
             // ---- pre-emphasis x window (src/io/in.cc:364-372), packed as z[n] = y[2n] + i y[2n+1]
             float *yb = reinterpret_cast<float *>(A);
-            double part = 0.0, raw = 0.0;
+            float partf = 0.f;  // a lane's 4..16 values in float (as the register kernels do), the block sum in double
+            double raw = 0.0;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int i = tid + 256 * it;
@@ -92,11 +93,12 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 if (i < p.window) {
                     const float xi = (float)cur[it];
                     y = lwin[i] * (xi - p.preem * (float)prv[it]);
-                    part += (double)y;
-                    if (i >= 1) raw += (double)xi * (double)xi;
+                    partf += y;
+                    if (p.e_mode == 4 && i >= 1) raw += (double)xi * (double)xi;
                 }
                 yb[i] = y;
             }
+            const double part = (double)partf;
             if (f + 1 < rec.nvalid) fetch(f + 1);
             if (p.remove_dc) {  // src/io/in.cc:375-382
                 const float m = (float)(block_sum(part, red) / (double)p.window);
@@ -156,7 +158,17 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 if (b < p.B) {
                     const int k0 = lrange[3 * b], k1 = lrange[3 * b + 1];
                     const float *w = lfb + lrange[3 * b + 2] - k0;
-                    for (int k = k0 + q; k <= k1; k += 4) acc += w[k] * P[k];
+                    // four independent partial sums: the reads of a step are in flight together
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    int k = k0 + q;
+                    for (; k + 12 <= k1; k += 16) {
+                        a0 += w[k] * P[k];
+                        a1 += w[k + 4] * P[k + 4];
+                        a2 += w[k + 8] * P[k + 8];
+                        a3 += w[k + 12] * P[k + 12];
+                    }
+                    for (; k <= k1; k += 4) a0 += w[k] * P[k];
+                    acc = (a0 + a1) + (a2 + a3);
                 }
                 acc += __shfl_xor(acc, 1);
                 acc += __shfl_xor(acc, 2);
@@ -177,11 +189,20 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 const int out_w = p.band_to_scratch ? p.B : p.D;
                 if (tid < p.B) dst_[row * out_w + tid] = p.band_log ? Ylog[tid] : Y[tid];
             } else if (p.feat == FEAT_DCTC) {
-                if (tid < p.ncoef_out && p.row_slot[tid] >= 0) {
-                    const float *c = lcoef + tid * p.B;
+                // 16 lanes per coefficient (ncoef_out <= 16 here or the remaining rows take a second round): lane j sums bands
+                // j, j+16, ..., then four shuffle steps
+                for (int r0_ = 0; r0_ < p.ncoef_out; r0_ += 16) {
+                    const int r = r0_ + (tid >> 4), j = tid & 15;
                     float acc = 0.f;
-                    for (int b = 0; b < p.B; b++) acc += c[b] * Ylog[b];
-                    p.rows[row * p.D + tid] = acc;
+                    if (r < p.ncoef_out) {
+                        const float *c = lcoef + r * p.B;
+                        for (int b = j; b < p.B; b += 16) acc += c[b] * Ylog[b];
+                    }
+                    acc += __shfl_xor(acc, 1);
+                    acc += __shfl_xor(acc, 2);
+                    acc += __shfl_xor(acc, 4);
+                    acc += __shfl_xor(acc, 8);
+                    if (j == 0 && r < p.ncoef_out && p.row_slot[r] >= 0) p.rows[row * p.D + r] = acc;
                 }
             } else if (tid == 0) {
                 // LP analysis in double by one lane (src/fea/fea_impl.cc:163-222, 251-284): R by cosine iDFT, Levinson-Durbin, a -> c
