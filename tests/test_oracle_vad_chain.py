@@ -1,0 +1,42 @@
+"""The oracle's restatement of the VAD behind a delta / stacking chain and behind CMS (src/io/batch.cc:172-241), pinned by
+relations that do not depend on how it is written: with a memoryless threshold and no median filter the detector's byte for
+call m is the plain detector's byte for input frame min(m + delay, T-1); CMS changes rows, not decisions."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.util import C2, synth_utt
+
+MEMORYLESS = "-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode absolute -vad_filter_order 1".split()
+
+
+@pytest.mark.parametrize("chain,delay", [(["-fea_delta", "d"], 2), (["-fea_delta", "d_a"], 4), (["-fea_delta", "d_a_t"], 6),
+                                         (["-fea_delta", "d", "-d_win", "5"], 5), (["-fea_trap", "9"], 4)])
+def test_detector_behind_a_chain_sees_the_newest_input_frame(chain, delay):
+    u = synth_utt(77, 30000)
+    # pick a threshold that splits the frames: scan a few levels until both decisions occur in the plain run
+    for level in (150.0, 160.0, 170.0, 175.0, 180.0, 185.0, 190.0, 195.0):
+        cfg = C2 + MEMORYLESS + ["-vad_absolute_thr", str(level)]
+        _, plain = Oracle(cfg).process(u, want_vad=True)
+        if 0.2 < (plain == ord("1")).mean() < 0.8:
+            break
+    else:
+        pytest.skip("no splitting threshold found")
+    rows, chained = Oracle(cfg + chain).process(u, want_vad=True)
+    T = plain.size
+    assert chained.size == T and rows.shape[0] == T
+    want = plain[np.minimum(np.arange(T) + delay, T - 1)]
+    assert np.array_equal(chained, want)
+
+
+def test_cms_leaves_the_spectral_criteria_alone():
+    u = synth_utt(78, 30000)
+    base = C2 + "-vad_out_mode vad -vad_cri_mode energy".split()
+    r0, v0 = Oracle(base).process(u, want_vad=True)
+    r1, v1 = Oracle(base + ["-fea_Z_exp", "1500"]).process(u, want_vad=True)
+    assert np.array_equal(v0, v1) and r0.shape == r1.shape and not np.allclose(r0[:, :12], r1[:, :12])
+    # and dropping rows happens after the subtraction: the kept rows are the CMS rows of the kept frames
+    r2, v2 = Oracle(base + ["-fea_Z_exp", "1500", "-vad_apply_mode", "drop"]).process(u, want_vad=True)
+    assert np.array_equal(v2, v1)
+    keep = v1 == ord("1")
+    assert r2.shape[0] == int(keep.sum())
