@@ -8,6 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "libctu_engine.so")
 CLI = os.path.join(ROOT, "bin", "ctucopy")
+SYNTH_LIB = os.path.join(HERE, "libctu_synth.so")  # the input generator alone (include/ctu_synth.h): no HIP runtime behind it
 
 ENGINE_SRCS = ["engine.hip", "opts.cc", "design.cc", "synth.cc"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -36,6 +37,16 @@ def build_engine(force=False, verbose=False):
     return LIB
 
 
+def build_synth(force=False):
+    """The synthetic-set generator as a library of its own (g++ only): processes that never touch the GPU - the CPU
+    baseline's workers, fixture scripts - load this instead of the HIP-linked engine library."""
+    src = os.path.join(CSRC, "synth.cc")
+    if force or _newer(SYNTH_LIB, [src, os.path.join(ROOT, "include", "ctu_synth.h")]):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"), src,
+                        "-o", SYNTH_LIB], check=True)
+    return SYNTH_LIB
+
+
 def build_cli(force=False):
     if not os.path.isdir(HOST):
         return None
@@ -54,6 +65,7 @@ def build_cli(force=False):
 
 def build_all(force=False):
     build_engine(force)
+    build_synth(force)
     build_cli(force)
 
 

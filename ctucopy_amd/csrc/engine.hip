@@ -85,8 +85,9 @@ struct ctu_engine {
     std::unique_ptr<ctu::Design> design;
     int device = 0;
     int n_cu = 256;
+    int user_wfft = 0, user_K = 0;
     int kstride = 1;            // > 1: an FFT size below 256 carried by the 256-point mode (ctu_engine_create)
-    std::string err;
+    std::string err, kname;
     int feat = FEAT_DCTC;
     int nz = 16;
     int mode = 0;  // 0: 512-point FFT, 1: 256-point FFT (two frames per complex transform)
@@ -112,6 +113,8 @@ struct ctu_engine {
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool host_timed = false;    // the last run was a host run cut into ranges: host_kernel_ms = sum over the ranges' front-end launches
+    float host_kernel_ms = 0.f;
     bool in_signal_call = false;
     // CMVN (row N2): statistic slot <-> row column maps, and per-call scratch
     std::vector<int> col_of_slot, slot_of_col;
@@ -140,6 +143,7 @@ struct ctu_plan {
     // the upload of one range overlaps the kernels and the download of the previous one (ctu_engine_run_host)
     std::vector<std::unique_ptr<ctu_plan>> parts;
     std::vector<int> part_first;       // first utterance of every part, n_utt at the end
+    int parts_for = 0;                 // the range count `parts` was built for (ctu_engine_run_host)
     hipStream_t part_stream[2] = {nullptr, nullptr};
     ~ctu_plan() {
         for (hipStream_t st : part_stream)
@@ -897,6 +901,8 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
         // 256-point spectrum, because the frame is zero beyond the window either way.  The engine runs the 256-point mode
         // with the filter bank spread onto those bins (zero weight in between); sums over bins step by kstride.
         ctu::Design &d = *e->design;
+        e->user_wfft = d.wfft;  // what ctu_engine_dims reports: the configuration's own FFT size and bin count (= ctu_config_dims)
+        e->user_K = d.K;
         if (d.wfft < 256 && d.wfft >= 32 && !d.signal_out) {
             const int S = 256 / d.wfft;
             e->kstride = S;
@@ -989,6 +995,8 @@ const char *ctu_last_error(const ctu_engine *e) { return e ? e->err.c_str() : "n
 int ctu_engine_dims(const ctu_engine *e, ctu_dims *out) {
     if (!e || !out) return CTU_ERR_INPUT;
     fill_dims(*e->design, out);
+    out->wfft = e->user_wfft;
+    out->nbins = e->user_K;
     return CTU_OK;
 }
 
@@ -1321,34 +1329,49 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const size_t nk = (size_t)pl->n_utt * d.K;
             std::vector<float> seed(nk, 0.f), last(nk, 0.f), next(nk, 0.f);
             if (e->ss_stale.size() != (size_t)d.K) e->ss_stale.assign(d.K, 0.f);
-            // files ahead of the first one with a frame start from what the previous run left (the reference keeps the
-            // vector for the life of the process, base/types.h:35-38, nr.cc:217-220)
-            for (int i = 0; i < pl->n_utt; i++) {
-                std::memcpy(&seed[(size_t)i * d.K], e->ss_stale.data(), d.K * sizeof(float));
-                if (pl->frames[i] > 0) break;
-            }
-            next = seed;
-            int last_live = -1;
-            for (int i = 0; i < pl->n_utt; i++)
-                if (pl->frames[i] > 0) last_live = i;
+            // new_file() seeds the estimate from the vector and then scales the vector by 0.1 (nr.cc:217-220, 402-407); a
+            // file with a frame overwrites it in its first get_frame(), a file without one (window - wshift <= N < window)
+            // leaves it scaled.  So file i starts from what the last file with a frame ahead of it left - or, ahead of the
+            // first such file, what the previous run left (the reference keeps the vector for the life of the process,
+            // base/types.h:35-38) - times 0.1 for every frameless file in between.
+            auto scaled = [&](float *dst, const float *src, int skipped) {
+                double f = 1.0;
+                for (int z = 0; z < skipped; z++) f *= 0.1;
+                for (int k = 0; k < d.K; k++) dst[k] = (float)((double)src[k] * f);
+            };
+            auto propagate = [&](std::vector<float> &dst) {  // seeds of every file from `last` (files with frames) and e->ss_stale
+                int prev = -1, skipped = 0;
+                for (int i = 0; i < pl->n_utt; i++) {
+                    scaled(&dst[(size_t)i * d.K], prev >= 0 ? &last[(size_t)prev * d.K] : e->ss_stale.data(), skipped);
+                    if (pl->frames[i] > 0) {
+                        prev = i;
+                        skipped = 0;
+                    } else
+                        skipped++;
+                }
+                return std::make_pair(prev, skipped);
+            };
+            propagate(seed);  // `last` is still zero: only the seeds ahead of the first file with a frame are final
             for (int iter = 0;; iter++) {
                 HIP_TRY(hipMemcpyAsync(pl->ss_seed.p, seed.data(), nk * sizeof(float), hipMemcpyHostToDevice, s));
                 launch();
                 HIP_TRY(hipMemcpyAsync(last.data(), pl->ss_last.p, nk * sizeof(float), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                int prev = -1;  // the last file before this one that had a frame: its vector is what new_file() finds
-                for (int i = 0; i < pl->n_utt; i++) {
-                    if (prev >= 0) std::memcpy(&next[(size_t)i * d.K], &last[(size_t)prev * d.K], d.K * sizeof(float));
-                    if (pl->frames[i] > 0) prev = i;
-                }
+                propagate(next);
                 if (std::memcmp(next.data(), seed.data(), nk * sizeof(float)) == 0) break;
                 if (iter > pl->n_utt) throw std::runtime_error("internal: noise seeds of the *ss chain did not settle");
                 seed = next;
             }
-            if (last_live >= 0) std::memcpy(e->ss_stale.data(), &last[(size_t)last_live * d.K], d.K * sizeof(float));
+            {   // what this run leaves for the next one
+                const auto tail = propagate(next);
+                std::vector<float> keep(d.K);
+                scaled(keep.data(), tail.first >= 0 ? &last[(size_t)tail.first * d.K] : e->ss_stale.data(), tail.second);
+                e->ss_stale = keep;
+            }
         }
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
+        e->host_timed = false;
         HIP_TRY(hipGetLastError());
 #if CTU_STAMP
         if (const char *sf = getenv("CTU_STAMP_FILE")) {
@@ -1509,7 +1532,8 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm
         // DMA-ed asynchronously at the link rate; pageable memory goes through the runtime's own staging (hipMemcpy).
         const bool pin_in = is_pinned(h_pcm), pin_out = is_pinned(h_rows);
         const int nparts = host_chunks(e, pl, pin_in && pin_out);
-        if (nparts > 1 && (int)pl->parts.size() != nparts) {
+        if (nparts > 1 && pl->parts_for != nparts) {  // keyed on the count asked for: fewer ranges may come out (a long utterance spans several)
+            pl->parts_for = nparts;
             // ranges of about equal PCM; a part's arena is the slice of the caller's arena that starts PCM_HEAD samples
             // ahead of its first utterance (the layout rule of ctu_plan_create is translation invariant)
             pl->parts.clear();
@@ -1535,6 +1559,7 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm
         std::vector<uint8_t> v(e->do_vad ? (size_t)pl->total_frames : 0);
         if (nparts > 1 && pl->parts.size() > 1) {
             const int np = (int)pl->parts.size();
+            std::vector<std::pair<hipEvent_t, hipEvent_t>> part_events;  // (start, stop) of every range's front-end launch
             auto download = [&](int k) {
                 ctu_plan *sp = pl->parts[k].get();
                 if (sp->total_frames == 0) return;
@@ -1557,13 +1582,35 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm
                     if (pin_in) HIP_TRY(hipMemcpyAsync(sp->h_pcm.p, src, (size_t)sp->total_samples * 2, hipMemcpyHostToDevice, st));
                     else HIP_TRY(hipMemcpy(sp->h_pcm.p, src, (size_t)sp->total_samples * 2, hipMemcpyHostToDevice));
                     const int rc = ctu_engine_run(e, sp, sp->h_pcm.p, sp->h_rows.p, sp->h_vad.p, st);
-                    if (rc != CTU_OK) return rc;
+                    if (rc != CTU_OK) {  // earlier ranges are still in flight on the two streams: drain them before the caller reuses its buffers
+                        (void)hipStreamSynchronize(pl->part_stream[0]);
+                        (void)hipStreamSynchronize(pl->part_stream[1]);
+                        for (auto &pe : part_events) {
+                            (void)hipEventDestroy(pe.first);
+                            (void)hipEventDestroy(pe.second);
+                        }
+                        return rc;
+                    }
+                    // the engine's event pair is re-recorded by every range: keep the sum (ctu_engine_last_kernel_ms after a host run)
+                    part_events.emplace_back();
+                    HIP_TRY(hipEventCreate(&part_events.back().first));
+                    HIP_TRY(hipEventCreate(&part_events.back().second));
+                    std::swap(part_events.back().first, e->ev0);
+                    std::swap(part_events.back().second, e->ev1);
                 }
                 if (k > 0) download(k - 1);  // behind the launch of part k: the copy engines and the kernels overlap
             }
             download(np - 1);
             HIP_TRY(hipStreamSynchronize(pl->part_stream[0]));
             HIP_TRY(hipStreamSynchronize(pl->part_stream[1]));
+            e->host_kernel_ms = 0.f;
+            for (auto &pe : part_events) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, pe.first, pe.second) == hipSuccess) e->host_kernel_ms += ms;
+                (void)hipEventDestroy(pe.first);
+                (void)hipEventDestroy(pe.second);
+            }
+            e->host_timed = true;
             if (e->do_vad)
                 for (int k = 0; k < np; k++)
                     if (pl->parts[k]->total_frames)
@@ -1826,8 +1873,29 @@ int ctu_engine_reset_chain(ctu_engine *e) {
     return CTU_OK;
 }
 
+const char *ctu_engine_kernel_name(const ctu_engine *e) {
+    if (!e) return "";
+    if (e->kname.empty()) {
+        const ctu::Design &d = *e->design;
+        const ctu::Opts &o = d.o;
+        std::string n;
+        if (e->big) n = "bigfft_kernel<" + std::to_string(d.wfft / 256) + ">";
+        else {
+            const char *feat = e->feat == FEAT_DCTC ? "DCTC" : e->feat == FEAT_BANDS ? "BANDS" : e->feat == FEAT_LP ? "LP" : "LPD";
+            const bool exten = o.nr_mode == "exten" && !o.nr_when_afterFB;
+            const bool plain = plain_cepstral(d) || (!o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.nr_when_afterFB && !d.signal_out);
+            n = "frontend_kernel<" + std::to_string(o.remove_dc1 ? 16 : e->nz) + ", " + feat + ", MODE " + std::to_string(e->mode) + ", " +
+                (e->sy ? "full" : !plain ? "full" : exten ? "exten" : o.fb_inld ? "inld" : "plain") + (e->md ? ", MD" : "") + (e->vf ? ", VF" : "") +
+                (e->ss ? ", SS" : "") + (e->sy ? ", SY" : "") + ">";
+        }
+        const_cast<ctu_engine *>(e)->kname = n;
+    }
+    return e->kname.c_str();
+}
+
 float ctu_engine_last_kernel_ms(ctu_engine *e) {
     if (!e || !e->timed) return -1.f;
+    if (e->host_timed) return e->host_kernel_ms;
     float ms = -1.f;
     if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.f;
     if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.f;

@@ -5,6 +5,7 @@ There is no CPU fallback: creating an Engine without the built library or withou
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -31,7 +32,7 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
 
@@ -80,6 +81,8 @@ def load_library():
     L.ctu_host_free.argtypes = [vp]
     L.ctu_engine_last_kernel_ms.restype = ctypes.c_float
     L.ctu_engine_last_kernel_ms.argtypes = [vp]
+    L.ctu_engine_kernel_name.restype = ctypes.c_char_p
+    L.ctu_engine_kernel_name.argtypes = [vp]
     L.ctu_cmvn_cols.argtypes = [vp]
     L.ctu_cmvn_accumulate.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.ctu_cmvn_apply.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
@@ -101,23 +104,11 @@ def host_alloc(shape, dtype):
     if not ptr:
         raise CtuError(CTU_ERR_DEVICE, "ctu_host_alloc failed")
     buf = (ctypes.c_char * n).from_address(ptr)
-    arr = np.frombuffer(buf, dtype=dtype).reshape(shape).view(_PinnedArray)
-    arr._owner = _Pinned(ptr)  # frees the block when the array goes away (views keep it alive through .base)
-    return arr
-
-
-class _PinnedArray(np.ndarray):
-    _owner = None
-
-
-class _Pinned:
-    def __init__(self, ptr):
-        self.ptr = ptr
-
-    def __del__(self):
-        if self.ptr:
-            load_library().ctu_host_free(self.ptr)
-            self.ptr = None
+    # The block lives as long as the ctypes object every derived array ends up holding as its buffer: np.asarray(),
+    # np.ascontiguousarray(), slices and .view() of the result all keep `buf` reachable through .base, whatever happens to
+    # the first array object (an owner attribute on an ndarray subclass is dropped by those calls while DMA may still run).
+    weakref.finalize(buf, L.ctu_host_free, ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def _argv(args):
@@ -306,6 +297,9 @@ class Engine:
 
     def last_kernel_ms(self):
         return float(load_library().ctu_engine_last_kernel_ms(self._h))
+
+    def kernel_name(self):
+        return load_library().ctu_engine_kernel_name(self._h).decode()
 
     def extract(self, utterances, want_vad=False):
         """Convenience: list of int16 arrays -> list of [rows, D] float32 arrays (and the VAD byte strings)."""

@@ -304,10 +304,18 @@ void write_wave(const std::string &path, const std::vector<int16_t> &x, int fs) 
 int real_main(int argc, char **argv) {
     std::vector<std::string> args;
     int ngpu = 1;
+    std::vector<int> gpu_map;  // --gpu-map a,b,...: device ordinal of every engine (default 0 .. N-1); an ordinal may repeat, which puts
+                               // several engines on one device - the multi-engine host path rehearsed on a box with fewer GPUs
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = std::max(1, std::atoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--gpu-map") && i + 1 < argc) {
+            std::istringstream ms(argv[++i]);
+            std::string tok;
+            while (std::getline(ms, tok, ',')) gpu_map.push_back(std::atoi(tok.c_str()));
+        }
         else args.emplace_back(argv[i]);
     }
+    if (!gpu_map.empty() && (int)gpu_map.size() != ngpu) throw Fatal("ENGINE: --gpu-map needs one device ordinal per engine of --gpus");
     ctu::Opts o;
     try {
         o = ctu::Opts::from_args(args);
@@ -359,7 +367,7 @@ int real_main(int argc, char **argv) {
     for (auto &a : args) cargs.push_back(a.c_str());
     std::vector<Gpu> gpus(ngpu);
     for (int g = 0; g < ngpu; g++)
-        if (ctu_engine_create((int)cargs.size(), cargs.data(), g, &gpus[g].eng) != CTU_OK) throw Fatal(ctu_create_error());
+        if (ctu_engine_create((int)cargs.size(), cargs.data(), gpu_map.empty() ? g : gpu_map[g], &gpus[g].eng) != CTU_OK) throw Fatal(ctu_create_error());
     ctu_dims d;
     ctu_engine_dims(gpus[0].eng, &d);
 

@@ -2,7 +2,7 @@
 
 Integer arithmetic only, so this numpy definition and the C one (ctucopy_amd/csrc/synth.cc, include/ctu_synth.h) give
 the same int16 samples bit for bit (tests/test_synth.py).  `utterance` is the readable definition; `fill_arena` calls
-the C implementation in libctu_engine.so (threads) for the benchmark's 10 000 utterances.
+the C implementation (csrc/synth.cc, built on its own as libctu_synth.so; threads) for the benchmark's 10 000 utterances.
 """
 import ctypes
 
@@ -93,9 +93,20 @@ def utterance(set_id, index, mini=False):
     return np.clip(x, -32768, 32767).astype(np.int16)
 
 
+_synth = None
+
+
 def _lib():
-    from .engine import load_library
-    L = load_library()
+    """ctucopy_amd/libctu_synth.so: csrc/synth.cc on its own (the engine library exports the same symbols for C callers,
+    but loading it pulls in the HIP runtime - the CPU baseline's workers must not pay for that, nor initialise it)."""
+    global _synth
+    if _synth is None:
+        import os
+        from . import build as _build
+        if not os.path.exists(_build.SYNTH_LIB):  # built by __graft_entry__.build(); never rebuilt here (many processes load it at once)
+            _build.build_synth()
+        _synth = ctypes.CDLL(_build.SYNTH_LIB)
+    L = _synth
     if not getattr(L, "_synth_ready", False):
         L.ctu_synth_length.restype = ctypes.c_int64
         L.ctu_synth_length.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]

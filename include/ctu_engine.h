@@ -84,7 +84,9 @@ int64_t ctu_num_frames(const ctu_engine *, int64_t nsamples);
 
 /* A plan fixes the batch layout: utterance i has utt_nsamples[i] samples and lives in the packed
  * int16 arena at sample offset ctu_plan_sample_offsets()[i] (offsets are multiples of pcm_align; the
- * gaps are never read).  Its output rows start at row ctu_plan_row_offsets()[i].  Both offset arrays
+ * arena has 8 samples of padding ahead of the first utterance and 512 behind the last one, and frames DO read past the
+ * end of their window - into the gap, the next utterance or that padding - under zero weights: every byte of
+ * ctu_plan_total_samples() must be readable, its contents between utterances do not matter).  Its output rows start at row ctu_plan_row_offsets()[i].  Both offset arrays
  * have n_utt+1 entries and stay valid until ctu_plan_destroy. */
 int ctu_plan_create(ctu_engine *, const int64_t *utt_nsamples, int32_t n_utt, ctu_plan **out);
 void ctu_plan_destroy(ctu_plan *);
@@ -125,6 +127,9 @@ int ctu_engine_reset_chain(ctu_engine *);
 /* Timing of the last ctu_engine_run on this engine, measured with HIP events on the run's stream
  * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */
 float ctu_engine_last_kernel_ms(ctu_engine *);
+/* Name of that kernel: the instantiation this engine's configuration runs its front end on (profiles and the bench's roofline
+ * line are keyed by it).  Valid for the life of the engine. */
+const char *ctu_engine_kernel_name(const ctu_engine *);
 
 /* ---- per-speaker CMVN over rows that are resident on the device -----------------------------------------------
  * Replaces cmvn_POST::sum_fea / stat_cm / sum_cv / stat_cv / process_frame (src/fea/post_impl.cc:51-118) and the

@@ -1357,7 +1357,11 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         ss_nr = calloc(K, sizeof(double));
         ss_re = malloc(sizeof(double) * K); ss_im = malloc(sizeof(double) * K);
         ss_t = malloc(sizeof(double) * wfft); ss_w1 = malloc(sizeof(double) * wfft); ss_w2 = malloc(sizeof(double) * wfft);
-        for (int i = 0; i < K; i++) Navg[i] = c->ss_mode == 3 ? c->ss_stale[i] : pow(c->ss_stale[i], o->nr_a);
+        for (int i = 0; i < K; i++) {
+            Navg[i] = c->ss_mode == 3 ? c->ss_stale[i] : pow(c->ss_stale[i], o->nr_a);
+            c->ss_stale[i] *= 0.1; /* nr.cc:219, :406 "init phase -> out = 0.1 * in": the first get_frame() overwrites the vector, but a file
+                                      without a frame (window - wshift <= N < window) leaves it scaled for the file behind it */
+        }
     }
     int lporder = o->fea_lporder;
     double *RRe = calloc(lporder + 2, sizeof(double)), *rc = calloc(lporder + 2, sizeof(double));

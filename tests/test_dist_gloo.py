@@ -10,20 +10,26 @@ from ctucopy_amd import shard
 
 
 def _worker(rank, world, port, q):
+    """What bench.py does per rank, minus the GPU: ONE seeded list, identical on every rank, partitioned by
+    longest-processing-time; the rank keeps its own part; only the timing and the frame count are reduced."""
+    from ctucopy_amd import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lens = shard.rank_shard(rank, 100)
-    frames = int(((lens - 240) // 160).sum())
+    n_list = 150 * world
+    lens = synth.lengths(synth.SET_SPEECH, np.arange(n_list))
+    frames_all = (lens - 240) // 160
+    mine = shard.lpt_shard(frames_all, world)[rank]
+    frames = int(frames_all[mine].sum())
     dt = 0.5 + 0.25 * rank                      # rank 1 is the slow one
     dist.barrier()
     tmax, fsum = shard.reduce_timing(dt, frames)
-    q.put((rank, lens[:3].tolist(), frames, tmax, fsum))
+    q.put((rank, mine.tolist(), frames, tmax, fsum, int(frames_all.sum())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_weak_scaling_reduction():
+def test_two_ranks_shard_one_list_and_reduce_timing():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
@@ -34,11 +40,11 @@ def test_two_rank_weak_scaling_reduction():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, l0, f0, t0, s0), (r1, l1, f1, t1, s1) = res
-    assert l0 != l1                              # ranks own different utterances
+    (r0, m0, f0, t0, s0, tot0), (r1, m1, f1, t1, s1, tot1) = res
+    assert sorted(m0 + m1) == list(range(300)) and not set(m0) & set(m1)   # the list is covered once, ranks own different utterances
     assert t0 == t1 == 0.75                      # max over ranks
-    assert s0 == s1 == f0 + f1                   # whole-job frames
-    assert f0 == int(((shard.rank_shard(0, 100) - 240) // 160).sum())
+    assert s0 == s1 == f0 + f1 == tot0 == tot1   # whole-job frames
+    assert abs(f0 - f1) <= 1500                  # LPT: the loads differ by at most one utterance (<= 15 s = 1498 frames)
 
 
 def test_split_list_covers_everything_once():

@@ -629,6 +629,32 @@ def test_spectral_subtraction_with_burg_detector(Engine, extra):
     assert not np.allclose(alone, got[1], rtol=0, atol=1e-3)
 
 
+def test_spectral_subtraction_frameless_file_scales_the_seed(Engine):
+    # new_file() scales the stale vector by 0.1 after seeding from it (src/nr/nr.cc:219, :406); only a file without a frame
+    # lets that survive (the oracle's walk of the statement order: tests/test_oracle_ss.py)
+    cfg = SS8 + ["-nr_mode", "2fwss"]
+    utts = _ss_list()  # utts[5]: 120 samples = the pre-load and no hop
+    got = Engine(cfg).extract(utts)
+    orc = Oracle(cfg)
+    refs = [orc.process(u) for u in utts]
+    assert got[5].shape[0] == 0 and refs[5].shape[0] == 0
+    _assert_rows(got[6], refs[6], cfg + ["-nr_mode", "exten"])
+    without = Engine(cfg).extract(utts[:5] + utts[6:])
+    assert not np.allclose(without[5][:2], got[6][:2], rtol=1e-3, atol=0)   # the file behind it starts from a tenth of the vector
+    for cut in (5, 6):  # the scaled vector also survives from run to run
+        eng = Engine(cfg)
+        parts = eng.extract(utts[:cut]) + eng.extract(utts[cut:])
+        for a, b in zip(got, parts):
+            assert np.array_equal(a, b)
+    # two frameless files in a row, and one at the head of a later run
+    eng = Engine(cfg)
+    twice = eng.extract(utts[:6] + [utts[5]]) + eng.extract([utts[5], utts[6]])
+    orc2 = Oracle(cfg)
+    want = [orc2.process(u) for u in utts[:6] + [utts[5], utts[5], utts[6]]]
+    _assert_rows(twice[-1], want[-1], cfg + ["-nr_mode", "exten"])
+    assert not np.allclose(twice[-1][:2], got[6][:2], rtol=1e-3, atol=0)
+
+
 def test_spectral_subtraction_refusals(Engine):
     from ctucopy_amd import CtuError
     for cfg in (C2 + ["-nr_mode", "fwss", "-vad", "burg"],                    # 16 kHz: 512-point mode

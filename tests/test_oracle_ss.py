@@ -30,10 +30,34 @@ def test_the_noise_seed_chains_the_list():
     assert np.array_equal(Oracle(cfg).process(a), ra)            # first in a list = alone
     alone = Oracle(cfg).process(b)
     assert not np.allclose(alone[:5], rb[:5], rtol=1e-3)         # second file starts from the first file's last vector
-    o2 = Oracle(cfg)
-    o2.process(a)
-    o2.process(a[:150])                                          # a file without a frame leaves the vector untouched
-    assert np.array_equal(o2.process(b), rb)
+
+
+def test_a_file_without_a_frame_scales_the_stale_vector():
+    """new_file() seeds Navg from the spectrum vector and THEN scales that vector by 0.1 (src/nr/nr.cc:217-220, 402-407).
+    A file with a frame overwrites it in its first get_frame(); a file whose samples hold the pre-load but not one hop
+    (window - wshift <= N < window: new_file() runs, get_frame() fails at loadframe, src/io/in.cc:314) leaves 0.1 X behind,
+    so the file after it is seeded with (0.1 X)^a.  Walked literally for 2fwss, whose first frame has a closed form:
+    Navg = p s + (1-p) X0, Y = |X0 - Navg|, Nravg = (1-p) Y, out = |Y - Nravg| = p^2 |X0 - s| (nr.cc:411-442)."""
+    p = 0.9
+    cfg = BASE + ["-nr_mode", "2fwss", "-nr_p", str(p)]
+    a, b = synth.utterance(synth.SET_NOISY, 1, True), synth.utterance(synth.SET_NOISY, 4, True)
+    plain = Oracle(BASE)
+    window = plain.dims.window
+    plain.process(b[:window])
+    x0 = plain.last_power()                                      # spectrum of b's frame 0 as get_frame() leaves it
+    fb = plain.fbank()[0]
+    for skipped in (0, 1, 2):
+        o = Oracle(cfg)
+        o.process(a)
+        stale = o.last_power()                                   # what file a's last process_frame() left in the vector
+        for _ in range(skipped):
+            assert o.process(a[:150]).shape[0] == 0              # 150 samples: pre-load of 120 succeeds, no hop of 80 after it
+        got = o.process(b)[0].astype(np.float64)
+        want = fb @ (p * p * np.abs(x0 - 0.1 ** skipped * stale))
+        assert np.allclose(got, want, rtol=2e-6), skipped
+        if skipped:
+            wrong = fb @ (p * p * np.abs(x0 - stale))
+            assert not np.allclose(got, wrong, rtol=1e-3)        # the unscaled seed is measurably different
 
 
 def test_detector_modes_the_reference_rejects():
