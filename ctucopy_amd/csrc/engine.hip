@@ -191,7 +191,6 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (o.rasta) return "-nr_rasta";
         if (o.do_vad()) return "VAD together with signal output";
         if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
-        if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
         if (d.window % 2) return "odd window length with signal output";
         if (d.window < 32) return "window shorter than 32 samples";
         return "";
@@ -206,7 +205,7 @@ std::string unsupported_reason(const ctu::Design &d) {
     }
     if (o.nr_mode != "none" && o.nr_mode != "exten") {
         if (o.vadmode == "file") return "-vad file=...: one byte stream for all files, every byte but NUL counts as speech (src/nr/nr.cc:297-301)";
-        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (8 kHz, 25 ms window, -vad burg, 12 cepstral coefficients, plain chain)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg, 12 cepstral coefficients, plain chain)";
     }
     if (o.nr_when_afterFB) {
         if (d.post_order > 0 || d.cms || o.stat_cmvn || o.apply_cmvn || o.do_vad() || d.signal_out) return "-nr_when afterFB together with post-processing, VAD or signal output";
@@ -259,7 +258,6 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (d.B > 64) return "more than 64 bands with an FFT size above 512";
     }
     else if (d.wfft != 512 && d.wfft != 256) return "FFT size below 32";
-    if (d.wfft == 512 && d.wshift % 2) return "odd frame shift with the 512-point transform (frame starts must be 4-byte aligned)";
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
         if (o.fea_lporder >= d.B) return "LP order not below the number of bands: the normal equations are singular and the reference's output is rounding noise";
@@ -297,20 +295,25 @@ bool plain_cepstral(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     return !o.nr_when_afterFB && d.kind == ctu::FeaKind::Dctc && d.nfea <= 16 && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !d.signal_out;
 }
-// Burg-cepstral VAD criterion fused into the front end (vad_fused.h): 256-point mode, 200-sample window, 14 coefficients (the preset's detector)
+// the frame shapes the fused detector paths are built for: 8 kHz / 25 ms (256-point mode, two frames per complex transform) and
+// 16 kHz / 25 ms (512-point mode, 16 lanes x 25 samples) - vad_fused.h
+bool fused_frame_shape(const ctu::Design &d) {
+    return (d.wfft == 256 && d.window == VF_WINDOW) || (d.wfft == 512 && d.window == VF0_WINDOW);
+}
+// Burg-cepstral VAD criterion fused into the front end (vad_fused.h): 14 coefficients (the preset's detector)
 bool vf_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     return CTU_VF && CTU_MD && plain_cepstral(d) && o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" &&
-           d.wfft == 256 && o.vad_lpc_coefs == VF_NC && d.window == VF_WINDOW && d.post_order == 0;
+           fused_frame_shape(d) && o.vad_lpc_coefs == VF_NC && d.post_order == 0;
 }
 bool md_eligible(const ctu::Design &d) { return CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d)); }
-// hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 256-point mode, 200-sample window, the
+// hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 25 ms frames at 8 or 16 kHz, the
 // presets' 12 cepstral coefficients for the detector, the plain chain into cepstra or band energies
 int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode == "fwss" ? 2 : o.nr_mode == "2fwss" ? 3 : 0; }
 bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
-    return CTU_MD && ss_mode_of(o) && o.vadmode == "burg" && !o.nr_when_afterFB && d.wfft == 256 && d.window == VF_WINDOW &&
+    return CTU_MD && ss_mode_of(o) && o.vadmode == "burg" && !o.nr_when_afterFB && fused_frame_shape(d) &&
            o.fea_ncepcoefs == SS_NC && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !o.do_vad() && !d.signal_out &&
            !o.rasta && d.post_order == 0 && !d.cms && !o.stat_cmvn && !o.apply_cmvn;
 }
@@ -485,7 +488,7 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
         // Hann window of the *ss modes' detector, han[i] = 0.5 (1 - cos(2 * 3.141592653 / window * i)) (src/vdet/CepstralDet.h:133-136)
         t.han_off = (int)ft.size();
         const double m = 2 * 3.141592653 / d.window;
-        for (int i = 0; i < 16 * VF_SPL; i++) ft.push_back(i < d.window ? (float)(0.5 * (1 - std::cos(m * i))) : 0.f);
+        for (int i = 0; i < 16 * (d.wfft == 512 ? VF0_SPL : VF_SPL); i++) ft.push_back(i < d.window ? (float)(0.5 * (1 - std::cos(m * i))) : 0.f);
     }
     t.tab_floats = (int)ft.size();
     t.NS = NS;
@@ -723,7 +726,8 @@ void build_tables(ctu_engine *e) {
     e->lift_off = t.lift_off;
     e->ftab.upload(t.ft);
     e->itab.upload(t.it);
-    e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS + (d.o.nr_when_afterFB ? NWAVE * 128 : 0)) * sizeof(float);
+    e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS + (d.o.nr_when_afterFB ? NWAVE * 128 : 0) +
+                    ((e->vf || e->ss) && !e->mode ? NWAVE * VF0_STAGE : 0)) * sizeof(float);  // 512-point detector paths: staged frames per wave
     if (e->lds_bytes > 160 * 1024) throw std::runtime_error("configuration needs more than 160 KiB of LDS");
     if (d.kind == ctu::FeaKind::TrapDct) {
         std::vector<float> g(d.trap.begin(), d.trap.end());
@@ -790,18 +794,19 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
         if constexpr (NZ == 16) launch_nz<16, MODE, false, GEN_DC1>(e, grid, s, kp);
     }
     else if (e->ss) {
-        if constexpr (MODE == 1) {
-            if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
-            else if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, 1, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
+        if constexpr (MODE == 1 || NZ == 13) {
+            if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
+            else if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
             else throw std::runtime_error("internal: SS engine without an SS instantiation");
         }
+        else throw std::runtime_error("internal: SS engine without an SS instantiation");
     }
     else if (e->vf) {
-        if (!(kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.fb_inld && feat == FEAT_DCTC && narrow && MODE == 1 && e->md))
+        if (!(kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.fb_inld && feat == FEAT_DCTC && narrow && (MODE == 1 || NZ == 13) && e->md))
             throw std::runtime_error("internal: VF engine without the VF instantiation");
-        if constexpr (MODE == 1) {
-            if (kp.nr_exten) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_EXTEN, 0, true, true>, grid, s, kp);
-            else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, 1, false, 16, GEN_PLAIN, 0, true, true>, grid, s, kp);
+        if constexpr (MODE == 1 || NZ == 13) {
+            if (kp.nr_exten) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_EXTEN, 0, true, true>, grid, s, kp);
+            else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, true>, grid, s, kp);
         }
     }
     else if (e->md) {

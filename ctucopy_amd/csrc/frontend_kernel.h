@@ -64,12 +64,17 @@ namespace {
 // SY:     speech-enhancement output (row N3, sigOUT src/io/out.cc:405-434): the step's spectra after NR go back to the time
 //         domain in registers (the inverse of vad_fused.h with the synthesis conventions) and the frames are written for
 //         the overlap-add kernel; no spectra through HBM, no phase 2.
+// The fused detector paths of the 512-point mode (VF / SS with MODE 0) keep both passes' transform outputs and a 25-sample
+// lattice per lane alive: 256 VGPRs, one workgroup per CU (their staging area takes the LDS of the second one anyway).
+constexpr int fe_waves_per_simd(int mode, bool vf, bool ss) { return ((vf || ss) && mode == 0) ? 2 : CTU_LB; }
+
 template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false, bool SY = false>
-__global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
+__global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS)) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
     static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
-    static_assert(!VF || (MODE == 1 && !VX), "VF: 256-point mode, no spectrum export");
-    static_assert(!SS || (MODE == 1 && !VX && !VF && GEN == GEN_PLAIN), "SS: 256-point mode, plain chain");
+    static_assert(!VF || !VX, "VF: no spectrum export");
+    static_assert(!SS || (!VX && !VF && GEN == GEN_PLAIN), "SS: plain chain");
+    static_assert(!((VF || SS) && MODE == 0) || NZ == 13, "VF / SS in the 512-point mode: 400-sample windows (16 lanes x 25 samples)");
     static_assert(!SY || (!VX && !VF && !SS && (GEN == GEN_FULL || GEN == GEN_DC1)), "SY: run-time flags, no export");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
         // table read serves both, and every stage offers the scheduler two independent instruction streams - the kernel
         // is bound by dependent latency (LDS round trips, transcendental-free but long FMA chains) at four waves per SIMD,
         // not by issue.  The plain cepstral chain only (the headline instantiation).
-        constexpr bool DUAL = CTU_DUAL && MODE == 0 && GEN == GEN_PLAIN && MD && !VX && NZ < 16;
+        constexpr bool DUAL = CTU_DUAL && MODE == 0 && GEN == GEN_PLAIN && MD && !VX && NZ < 16 && !VF && !SS && !SY;
         if constexpr (DUAL) {
             if (nv > 0) {
                 float2 v0[16], v1[16];
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
             typedef std::remove_reference_t<decltype(out[0])> real_t;  // float, or double for the *ss detector (vad_fused.h)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (MODE == 1) {
             float2 vn[16];
             vf_scale_spectra(vz, vn, Pw + (2 * fg) * PSTRIDE, Pw + (2 * fg + 1) * PSTRIDE, l16, partner);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -533,6 +539,49 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
                 out[xb] = mine;
             }
+            } else {
+            // 512-point mode: one frame per 16-lane group, slots 0-3 (first pass) then 4-7.  Each half re-scales its bins to the
+            // magnitudes in its own P rows, runs the packed-real inverse through those rows (as the synthesis of row N3 does)
+            // and stages its four frames in the wave's area behind the tables; out[h]: lane 16 fg + i holds coefficient i of
+            // frame slot 4 h + fg.
+            float *const stage = ltw + LTW_FLOATS + wave * VF0_STAGE;
+            auto half_step = [&](const float2 (&vzz)[16], auto HALF) {
+                constexpr int half = decltype(HALF)::value;
+                float2 vn[16];
+                float *rows4 = Pw + 4 * half * PSTRIDE;
+                vf_scale_tangle0<false>(vzz, vn, rows4 + fg * PSTRIDE, ltw4, l16, partner, 2.f);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // every lane has its gains before the rows become transpose scratch
+                vf_inverse_fft(vn, ltw4, (uint32_t)(size_t)(lvoid_t *)rows4, rows4 + 65 * l16 + 16 * fg);
+                STAMP(11);
+                // z[n] = x[2n] + i x[2n+1], n = l16 + 16 m: the first 13 rows of 32 samples cover the window
+                float2 *ta = reinterpret_cast<float2 *>(stage + fg * VF0_FSTRIDE) + l16;
+#pragma unroll
+                for (int m = 0; m < 13; m++) ta[16 * m] = vn[m];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *tx = stage + fg * VF0_FSTRIDE + VF0_SPL * l16;
+                float x[VF0_SPL];
+                real_t cc[nco];
+#pragma unroll
+                for (int j = 0; j < VF0_SPL; j++) x[j] = (VF0_SPL * l16 + j < p.window) ? tx[j] : 0.f;  // the first `window` samples (src/vad/vad.cc:233)
+                if constexpr (decltype(HANN)::value) {
+                    const float *hw = ltab + p.han_off + VF0_SPL * l16;
+#pragma unroll
+                    for (int j = 0; j < VF0_SPL; j++) x[j] *= hw[j];
+                }
+                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL>(x, l16, VF0_LW, VF0_JW, (real_t)p.inv_window_d, cc);
+                real_t mine = cc[0];
+#pragma unroll
+                for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
+                out[half] = mine;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the staged frames are read before the next half overwrites them
+            };
+            half_step(vz, std::integral_constant<int, 0>{});
+            out[1] = out[0];
+            if (nv > 4) half_step(vz1, std::integral_constant<int, 1>{});
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             STAMP(12);  // VF / SS: frames re-laid, Burg lattice, cepstra
@@ -566,8 +615,9 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 // (2) the detector's recurrences over the step's frames, in order (src/vdet/CepstralDet.h:140-194)
                 unsigned vbits = 0;
                 for (int s_ = 0; s_ < nv; s_++) {
-                    const int src = ((16 * (s_ >> 1) + (lane & 15)) << 2);
-                    const double sel = (s_ & 1) ? mine_ab[1] : mine_ab[0];
+                    // frame slot s_: group s_ / 2, frame s_ % 2 of it (256-point mode); group s_ % 4 of half s_ / 4 (512-point mode)
+                    const int src = ((16 * (MODE == 1 ? (s_ >> 1) : (s_ & 3)) + (lane & 15)) << 2);
+                    const double sel = (MODE == 1 ? (s_ & 1) : (s_ >> 2)) ? mine_ab[1] : mine_ab[0];
                     const double got = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(sel)),
                                                         __builtin_amdgcn_ds_bpermute(src, __double2loint(sel)));
                     const double cil = lane < SS_NC ? got : 0.0;
@@ -1044,11 +1094,13 @@ __global__ __launch_bounds__(WG, CTU_LB) void frontend_kernel(const KParams p) {
                 if (rec.t0 == 0 && slot0 == 0) vad_run_reset(vrun);
                 uint8_t *vout = p.vad_out + (rbase - rec.t0);
                 // the coefficients of the next frame are fetched across the lanes while this frame's decision is worked out
+                // frame slot s: group s / 2, frame s % 2 of it (256-point mode); group s % 4 of half s / 4 (512-point mode)
                 float ca = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 15) << 2, __float_as_int(mine_ab[0])));
                 float cb = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 15) << 2, __float_as_int(mine_ab[1])));
                 for (int s_ = 0; s_ < nv; s_++) {
-                    const double cil = lane < VF_NC ? (double)((s_ & 1) ? cb : ca) : 0.0;
-                    const int srcn = ((16 * (((s_ + 1) & 7) >> 1) + (lane & 15)) << 2);
+                    const double cil = lane < VF_NC ? (double)((MODE == 1 ? (s_ & 1) : (s_ >> 2)) ? cb : ca) : 0.0;
+                    const int sn = (s_ + 1) & 7;
+                    const int srcn = ((16 * (MODE == 1 ? (sn >> 1) : (sn & 3)) + (lane & 15)) << 2);
                     const float nca = __int_as_float(__builtin_amdgcn_ds_bpermute(srcn, __float_as_int(mine_ab[0])));
                     const float ncb = __int_as_float(__builtin_amdgcn_ds_bpermute(srcn, __float_as_int(mine_ab[1])));
                     vad_frame(vrun, p.vad, rec.t0 + slot0 + s_, 0.0, cil, lane, vout);

@@ -284,8 +284,8 @@ __device__ __forceinline__ double lanes8_allreduce_add(double x) {
 struct __attribute__((packed, aligned(2))) pcm2 {  // two consecutive int16 samples at any sample address
     uint32_t v;
 };
-struct __attribute__((aligned(4))) pcm4 {  // four consecutive int16 samples, 4-byte aligned
-    uint32_t lo, hi;
+struct __attribute__((packed, aligned(2))) pcm4 {  // four consecutive int16 samples at any sample address: one global_load_dwordx2 either
+    uint32_t lo, hi;                                // way (global memory takes unaligned accesses), so odd frame shifts cost nothing
 };
 
 // Phase-2 helpers with a compile-time coefficient count (16 or MAXC) so that nothing branches per coefficient.

@@ -25,6 +25,13 @@ constexpr int VF_SPL = 13;        // samples per lane of a frame: 16 lanes x 13 
 constexpr int VF_LW = (VF_WINDOW - 1) / VF_SPL, VF_JW = (VF_WINDOW - 1) % VF_SPL;  // lane / register of the window's last sample
 constexpr int VF_FSTRIDE = 216;   // floats per time-domain frame in the LDS staging area: 2 x 216 = 16 (mod 32), so the two
                                   // frame groups of a half wave read different banks; 8 x 216 <= the wave's 8 x 260
+// The 512-point mode (16 kHz, 25 ms): one frame per 16-lane group, four frames per half step
+constexpr int VF0_WINDOW = 400;   // the window the fused path of the 512-point mode is built for
+constexpr int VF0_SPL = 25;       // 16 lanes x 25 = 400 samples
+constexpr int VF0_LW = (VF0_WINDOW - 1) / VF0_SPL, VF0_JW = (VF0_WINDOW - 1) % VF0_SPL;
+constexpr int VF0_FSTRIDE = 432;  // floats per staged frame: >= 416 (13 rows of 32 samples are written) and = 16 (mod 32): the two frame
+                                  // groups of a half wave read 25 l16 + j from different banks
+constexpr int VF0_STAGE = 4 * VF0_FSTRIDE;  // floats of staging per wave (behind the tables: these instantiations run one workgroup per CU)
 
 // Stage A.  vz[r] = Z[l16 + 16 r] of the forward transform of (frame A + i frame B).  Every bin is scaled to the
 // magnitude the noise reduction left (P rows of the two frames) while it keeps its direction:
@@ -76,8 +83,10 @@ __device__ __forceinline__ void vf_scale_spectra(const float2 (&vz)[16], float2 
 // k = l16 + 16 k2 and their mirrors; both are re-scaled to the magnitudes in `row` (times `scale`) and tangled back:
 //   s' = (u' + v') / 2,  t' = (u' - v') / 2,  d' = i conj(w) t',  Z'[k] = (s' + d') / 2,  Z'[256-k] = conj((s' - d') / 2)
 // The second one belongs to the mirror lane's register 15 - k2 and is exchanged by ds_bpermute (lane 0 owns its mirrors).
-// Synthesis conventions only (SYN): DC, Nyquist (bin 256) as positive reals.  HC2R's x = 2 * IDFT_256-sum(Z'): `scale`
-// carries that 2.
+// SYN: synthesis conventions - DC and Nyquist (bin 256) as positive reals (sigOUT, src/io/out.cc:416-419); otherwise the
+// detector's (src/vad/vad.cc:227-230 with the phases of src/io/in.cc:396-401): DC phase 0, Nyquist 0 or pi by the sign of its
+// real part.  HC2R's x = 2 * IDFT_256-sum(Z'): `scale` carries that 2.
+template <bool SYN = true>
 __device__ __forceinline__ void vf_scale_tangle0(const float2 (&vz)[16], float2 (&vn)[16], const float *row, const float4 *ltw4, int l16,
                                                  int partner, float scale) {
     float2 bp[8];
@@ -105,9 +114,9 @@ __device__ __forceinline__ void vf_scale_tangle0(const float2 (&vz)[16], float2 
         float upr = gu * ur, upi = gu * ui, vpr = gv * vr, vpi = gv * vi;
         if (!(mu > 0.f)) { upr = 0.f; upi = -2.f * tk; }      // c_ph(0, 0) = -pi/2: X' = -i t
         if (!(mv > 0.f)) { vpr = 0.f; vpi = 2.f * tm; }       // v' = conj(2 X'[256-k])
-        if (l16 == 0 && k2 == 0) {                             // bins 0 and 256: positive reals
+        if (l16 == 0 && k2 == 0) {                             // bins 0 and 256 are real: u = 2 X[0], v = 2 X[256]
             upr = 2.f * tk; upi = 0.f;
-            vpr = 2.f * tm; vpi = 0.f;
+            vpr = (SYN || vr >= 0.f) ? 2.f * tm : -2.f * tm; vpi = 0.f;
         }
         const float spr = 0.5f * (upr + vpr), spi = 0.5f * (upi + vpi), tpr = 0.5f * (upr - vpr), tpi = 0.5f * (upi - vpi);
         const float dpr = wi * tpr - wr * tpi, dpi = wr * tpr + wi * tpi;   // i conj(w) t'
@@ -168,8 +177,9 @@ __device__ __forceinline__ void vf_inverse_fft(float2 (&vn)[16], const float4 *l
 #ifndef CTU_BURG_DREC
 #define CTU_BURG_DREC 0  // 1: the denominator of order m+1 from that of order m, D' = (1 - k^2) D - f[m]^2 - b[N-1]^2, instead of the sum
 #endif
-template <int NC, int JW, class T>
-__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[VF_SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
+template <int NC, int JW, class T, int SPL = VF_SPL>
+__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
+    constexpr int VF_SPL = SPL;  // samples per lane (13: 256-point mode, 25: 512-point mode); shadows the global of the same name
     T ef[VF_SPL], eb[VF_SPL];
     T part = 0, part1 = 0;
 #pragma unroll

@@ -84,6 +84,20 @@ def test_ragged_batch_and_tile_edges(Engine):
         assert rel_err(g, orc.process(u)) <= TOL
 
 
+def test_odd_frame_shift(Engine):
+    # 161 samples per hop: every other frame starts on an odd sample (2-byte aligned loads of four samples)
+    cfg = C2 + ["-s", "10.0625"]
+    utts = [synth_utt(51, 20000), sig("CS0")[:30000]]
+    eng = Engine(cfg)
+    assert eng.dims.wshift == 161
+    _check(Engine, cfg, utts)
+    _check(Engine, C3 + ["-s", "10.0625"], utts[:1])
+    got = Engine("-fs 16000 -format_in raw -format_out raw -preset exten -s 16.0625".split()).enhance(utts[:1])[0]
+    from oracle.oracle import Oracle as O
+    ref = O("-fs 16000 -format_in raw -format_out raw -preset exten -s 16.0625".split()).enhance(utts[0])
+    assert got.shape == ref.shape and np.abs(got.astype(int) - ref.astype(int)).max() <= 2
+
+
 def test_batch_invariance(Engine):
     # an utterance's rows do not depend on what else is in the batch (bit-exact)
     eng = Engine(C2)
@@ -140,6 +154,34 @@ def test_host_runs_in_utterance_ranges(Engine, monkeypatch, chunks):
         for a, b, va, vb in zip(one, many, vone, vmany):
             assert a.shape == b.shape and np.array_equal(a, b)
             assert np.array_equal(va, vb)
+
+
+@pytest.mark.parametrize("chunks", ["1", "2", "5"])
+def test_host_runs_from_page_locked_buffers(Engine, monkeypatch, chunks):
+    # the asynchronous leg of ctu_engine_run_host: arena and rows from ctu_host_alloc, ranges DMA-ed on two streams; the
+    # buffers stay valid through derived arrays (np.asarray / slices keep the block alive), and the time of the front-end
+    # launches is the sum over the ranges
+    from ctucopy_amd.engine import host_alloc
+    utts = [synth_utt(400 + i, 9000 + 1777 * i) for i in range(11)]
+    monkeypatch.setenv("CTU_HOST_CHUNKS", "1")
+    eng = Engine(C2)
+    plan = eng.plan([len(u) for u in utts])
+    want = eng.run_host(plan, plan.pack(utts)).copy()
+    monkeypatch.setenv("CTU_HOST_CHUNKS", chunks)
+    eng2 = Engine(C2)
+    plan2 = eng2.plan([len(u) for u in utts])
+    arena = host_alloc((plan2.total_samples,), np.int16)
+    arena[:] = plan2.pack(utts)
+    rows = host_alloc((plan2.total_frames, eng2.dims.row_floats), np.float32)
+    view = np.asarray(rows)      # a plain ndarray over the same block
+    del rows
+    for _ in range(2):           # the second call reuses the cached ranges
+        view[:] = 0
+        got = eng2.run_host(plan2, arena, rows_out=view)
+        assert got is view and np.array_equal(view, want)
+        assert eng2.last_kernel_ms() > 0
+    del arena
+    assert np.array_equal(view, want)
 
 
 def test_remove_dc1(Engine):
@@ -277,16 +319,20 @@ def test_c4_burg_cepstral_vad(Engine):
     assert int((vads[0] == ord("1")).sum()) == 626   # the compiled reference wrote 626 ones
 
 
-@pytest.mark.parametrize("extra,min_agree", [
-    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "perc"], 0.995),
-    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "adapt"], 0.99),
-    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "dyn", "-vad_filter_order", "5"], 0.99),
-    (["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "absolute", "-vad_absolute_thr", "150"], 0.995),
-    (["-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "adapt"], 0.99),
-    (["-vad", "burg", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_thr_mode", "adapt"], 0.99),
+@pytest.mark.parametrize("extra", [
+    ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "perc"],
+    ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "adapt"],
+    ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "dyn", "-vad_filter_order", "5"],
+    ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "absolute", "-vad_absolute_thr", "150"],
+    ["-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "adapt"],
+    ["-vad", "burg", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_thr_mode", "adapt"],
 ])
-def test_vad_modes_16k(Engine, extra, min_agree):
-    _vad_agreement(Engine, C2 + extra, [sig("CS0")[:48000], synth_utt(92, 30000)], min_agree)
+def test_vad_modes_16k(Engine, extra):
+    # decisions are states, not a percentage: a flipped byte changes the thresholds' recurrences for the rest of the file, so
+    # every byte of every file must agree (tools/probes/ss_vad_err.py: 0 differing bytes on ten files for all six modes)
+    from ctucopy_amd import synth
+    files = [sig("CS0")[:48000], synth_utt(92, 30000), sig("CS3")[:48000]] + [synth.utterance_c(synth.SET_SPEECH, i, True) for i in range(3)]
+    _vad_agreement(Engine, C2 + extra, files, 1.0)
 
 
 def test_vad_drop_mode_row_counts(Engine):
@@ -617,14 +663,41 @@ def test_spectral_subtraction_with_burg_detector(Engine, extra):
     for u, g in zip(utts, got):
         ref = orc.process(u)
         assert g.shape == ref.shape
-        # the detector's decisions steer the noise estimate: a flipped frame would show as a gross error from there on
-        if "hwss" in cfg:
-            # half-wave rectification: max(X - b Navg, 0) cancels where speech is absent, and a band energy made of such bins
-            # carries err(X) X / (X - b Navg) of the fp32 spectrum: 2e-3 (no flips: the error does not grow along the file)
-            assert rel_err(g, ref) <= 2e-3, (rel_err(g, ref), " ".join(cfg))
-        else:
-            _assert_rows(g, ref, cfg + ["-nr_mode", "exten"])  # conditioning class of an NR configuration
+        # the detector's decisions steer the noise estimate: a flipped frame would show as a gross error from there on.  All three
+        # modes subtract nearly equal quantities: the conditioning class of an NR configuration (measured, tools/probes/
+        # ss_vad_err.py: hwss 2.1e-4 element-wise / 7e-7 of the row's largest value - half-wave rectification max(X - b Navg, 0)
+        # cancels where speech is absent and a band made of such bins carries err(X) X / (X - b Navg) of the fp32 spectrum)
+        _assert_rows(g, ref, cfg + ["-nr_mode", "exten"])
     # the chain is real: the same file alone (zero seed) comes out differently from its place in the list
+    alone = Engine(cfg).extract([utts[1]])[0]
+    assert not np.allclose(alone, got[1], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("extra", [["-nr_mode", "fwss"], ["-nr_mode", "2fwss"], ["-nr_mode", "hwss", "-fea_kind", "spec"],
+                                   ["-nr_mode", "fwss", "-nr_a", "2", "-nr_b", "1.5", "-fea_kind", "logspec"]])
+def test_spectral_subtraction_at_16khz(Engine, extra):
+    # the reference's shipped examples are 16 kHz (egs/conf): 512-point mode, one frame per 16-lane group, 25 samples per lane in
+    # the detector's lattice (frontend_kernel<13, ..., MODE 0, ..., SS>)
+    from ctucopy_amd import synth
+    cfg = C2 + ["-vad", "burg"] + extra
+    utts = [synth.utterance_c(synth.SET_SPEECH, i, True) for i in (1, 4, 6)] + [sig("CS0")[:40000], synth_utt(18, 240), sig("CS3")[:30000],
+                                                                                 synth_utt(21, 240 + 160 * 5 + 7)]
+    got = Engine(cfg).extract(utts)
+    orc = Oracle(cfg)
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        if "2fwss" in cfg and ref.size:
+            # two subtractions in a row, each of nearly equal quantities (|X - Navg| and then |. - Nravg|, nr.cc:420-437): where a
+            # frame's dominant bins meet the noise estimate to four digits the fp32 spectrum's 1e-6 comes out as 1e-2 - for that
+            # frame only, nothing propagates (measured, tools/probes/ss16_dbg.py: one frame of 248 on the CS0 recording, 3.4e-2;
+            # every other row within 6e-5).  Held to: the conditioning rule on all but at most one frame in 100, those below 5e-2.
+            e = (np.abs(g - ref) / np.maximum(np.abs(ref), 1.0)).max(axis=1)
+            rn = np.abs(g - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1.0)
+            out = (e > 1e-3) | (rn > 1e-4)
+            assert out.sum() <= max(1, ref.shape[0] // 100) and e.max() <= 5e-2, (int(out.sum()), float(e.max()))
+        else:
+            _assert_rows(g, ref, cfg + ["-nr_mode", "exten"])
     alone = Engine(cfg).extract([utts[1]])[0]
     assert not np.allclose(alone, got[1], rtol=0, atol=1e-3)
 
@@ -657,7 +730,7 @@ def test_spectral_subtraction_frameless_file_scales_the_seed(Engine):
 
 def test_spectral_subtraction_refusals(Engine):
     from ctucopy_amd import CtuError
-    for cfg in (C2 + ["-nr_mode", "fwss", "-vad", "burg"],                    # 16 kHz: 512-point mode
+    for cfg in (C2 + ["-nr_mode", "fwss", "-vad", "burg", "-w", "20"],        # a 320-sample window: not one of the fused frame shapes
                 SS8 + ["-nr_mode", "fwss", "-fea_ncepcoefs", "10"],          # detector order tied to -fea_ncepcoefs
                 SS8 + ["-nr_mode", "hwss", "-nr_when", "afterFB"]):
         with pytest.raises(CtuError) as ei:

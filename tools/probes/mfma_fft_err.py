@@ -213,6 +213,9 @@ for u in utts:
     got = mfcc(spectrum(u))
     e = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
     allerr.append(e.ravel()); worst = max(worst, e.max())
+    if os.environ.get("PERUTT"):
+        t_, c_ = np.unravel_index(e.argmax(), e.shape)
+        print(f"  utt len {u.size}: max {e.max():.3e} at frame {t_} coef {c_} (ref {ref[t_, c_]:.4f}); p99 {np.quantile(e, .99):.2e}; peak |x| {np.abs(u.astype(int)).max()}")
 e = np.concatenate(allerr)
 print(f"four={a.four} rtn={a.rtn} s1={a.s1} f64={a.f64}: entries {e.size} max {e.max():.3e} p99.9 {np.quantile(e, .999):.3e} p99 {np.quantile(e, .99):.3e} median {np.median(e):.3e}")
 if os.environ.get("DBG"):
@@ -247,3 +250,28 @@ if os.environ.get("DBG1"):
         full = sum(t @ (hi * a.s1) for t in t256) + sum(t @ (lo * a.s1) for t in t1[:nt - 1])   # float64 sums: matrix error only
         print(nt, "terms: matrix-only error / rms(exact):", np.abs(full - exact).max() / np.sqrt((exact ** 2).mean()))
     print("rms exact", np.sqrt((exact ** 2).mean()), "rms raw partial", np.sqrt(((Ap[:, 0::2] @ kp[0::2]) ** 2).mean()) * a.s1)
+if os.environ.get("DBG2"):
+    u = utts[0]
+    T = (u.size - (W - SH)) // SH
+    up = np.concatenate([[0], u.astype(np.int64), np.zeros(NF, dtype=np.int64)])
+    fr = np.stack([up[t * SH: t * SH + NF + 1] for t in range(T)])
+    xm1, x = fr[:, :-1], fr[:, 1:]
+    for n2 in (0, 5, 11):
+        i = 32 * np.arange(16) + 2 * n2
+        kk = np.vstack([x[:, i].T, xm1[:, i].T])
+        A = AE[n2] / a.s1
+        exact = A @ kk * a.s1
+        perm = np.arange(32).reshape(2, 16).T.ravel()
+        Ap, kp = A[:, perm], kk[perm]
+        for shift in (8, 6):
+            hi = kp >> shift; lo = kp - (hi << shift)
+            for nt, ntl in ((3, 2), (3, 3), (4, 3)):
+                tH = fsplit(Ap * float(1 << shift), nt); tL = fsplit(Ap, ntl)
+                chain = [(t, hi) for t in tH] + [(t, lo) for t in tL]
+                chain.sort(key=lambda c: np.abs(c[0]).max() * np.abs(c[1]).max())
+                acc = None
+                for M_, d_ in chain:
+                    acc = mm32(M_, d_ * a.s1, acc)
+                full = sum(M_ @ (d_ * a.s1) for M_, d_ in chain)
+                rms = np.sqrt((exact ** 2).mean())
+                print(f"n2 {n2} shift {shift} terms hi {nt} lo {ntl}: matrix-only err rms {np.sqrt(((full - exact) ** 2).mean()) / rms:.2e} max {np.abs(full - exact).max() / rms:.2e} | with fp32 acc: rms {np.sqrt(((acc - exact) ** 2).mean()) / rms:.2e} max {np.abs(acc - exact).max() / rms:.2e} | fp32(exact) rms {np.sqrt(((exact.astype(np.float32) - exact) ** 2).mean()) / rms:.2e}")
