@@ -38,6 +38,7 @@
 #include "trap_kernel.h"
 #include "decode_kernels.h"
 #include "bigfft_kernel.h"
+#include "lp_tail_kernel.h"
 
 namespace {
 
@@ -154,12 +155,16 @@ struct ctu_plan {
     DevBuf<float2> xri;         // VAD scratch
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
+    DevBuf<float> vad_cf;      // fused Burg-cepstral VAD: cepstra of every frame [total_frames][VFC_STRIDE] ahead of vad_lanes_kernel
+    DevBuf<int> vf_order;      // utterances with at least one frame, longest first (a wave of vad_lanes_kernel takes 64 in a row)
+    int n_live = 0;
     DevBuf<int64_t> d_row_off;
     DevBuf<double> dc1m;       // -remove_dc1: frame means, then
     DevBuf<float> dc1;         // the offsets the frames subtract (decode_kernels.h)
     int max_frames = 0;        // longest utterance of the plan
     // scratch between the kernels of one run; owned by the plan, so plans can run concurrently on different streams
     DevBuf<float> logmel;      // TRAP: log-mel rows [total_frames][B]
+    DevBuf<double> lp_r;       // LP kinds: autocorrelation lags [total_frames][lporder + 1] (used as float rows by the fp32 path) ahead of lp_tail_kernel
     DevBuf<float> base_rows;   // front-end rows ahead of the delta / stacking / CMS passes [total_frames][Dbase]
     DevBuf<float> ybuf;        // signal output: time-domain frames ahead of the overlap-add [total_frames][window]
     std::vector<int64_t> out_samples;   // signal output: samples written per utterance
@@ -959,7 +964,7 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             const ctu::Opts &o = e->design->o;
             const ctu::Design &d = *e->design;
             e->do_vad = o.do_vad();
-            e->per_wave = o.nr_mode == "exten" || e->vf || e->ss;  // state along an utterance (exten, the VAD's recurrences): a wave per chain
+            e->per_wave = o.nr_mode == "exten" || e->ss;  // state along an utterance (exten, the *ss modes): a wave per chain
             VadParams &vp = e->vp;
             std::memset(&vp, 0, sizeof vp);
             vp.K = d.K; vp.wfft = d.wfft; vp.window = d.window;
@@ -1133,6 +1138,16 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
                     pl->pnr.alloc((size_t)ro * d.K);
                 }
                 if (!e->vf) pl->vad_ci.alloc((size_t)ro * e->vp.ncoef);
+                else {
+                    pl->vad_cf.alloc((size_t)std::max<int64_t>(ro, 1) * VFC_STRIDE);
+                    std::vector<int> ord;
+                    for (int i = 0; i < n_utt; i++)
+                        if (pl->frames[i] > 0) ord.push_back(i);
+                    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return pl->frames[a] > pl->frames[b]; });
+                    pl->n_live = (int)ord.size();
+                    if (ord.empty()) ord.push_back(0);
+                    pl->vf_order.upload(ord);
+                }
             } else if (e->vp.cri == 0) pl->pnr.alloc((size_t)ro);
         }
         if (d.signal_out) {
@@ -1170,6 +1185,8 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             pl->trap_chunks128.upload(c128);
         }
         if (d.kind == ctu::FeaKind::TrapDct) pl->logmel.alloc((size_t)ro * d.B);
+        if ((d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) && !e->big)
+            pl->lp_r.alloc(((size_t)std::max<int64_t>(ro, 1) * (d.o.fea_lporder + 1) * (e->feat == FEAT_LPD ? 8 : 4) + 7) / 8);
         if (d.post_order > 0 || d.cms) pl->base_rows.alloc((size_t)ro * d.Dbase);
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
@@ -1224,8 +1241,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.ss_seed = pl->ss_seed.p;
         kp.ss_last = pl->ss_last.p;
         kp.tile_utt = pl->tile_utt.p;
-        kp.vad_out = d_vad;
-        kp.vad = e->vp;
+        kp.vad_cf = pl->vad_cf.p;
         kp.skip_phase2 = signal ? 1 : 0;
         kp.tiles = pl->tiles.p;
         kp.wg_first = pl->wg_first.p;
@@ -1256,6 +1272,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.D = d.Dbase;
         kp.ncep = d.o.fea_ncepcoefs;
         kp.lporder = d.o.fea_lporder;
+        kp.lp_r = pl->lp_r.p;
+        kp.lp_stride = d.o.fea_lporder + 1;
         kp.lift_off = e->lift_off;
         kp.preem = d.o.preem;
         kp.inv_window = 1.0f / (float)d.window;
@@ -1394,6 +1412,24 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             }
         }
 #endif
+        if ((e->feat == FEAT_LP || e->feat == FEAT_LPD) && !e->big && !signal) {
+            LpTailParams tp;
+            tp.lags = pl->lp_r.p;
+            tp.rows = kp.rows;
+            tp.lifter = e->ftab.p + e->lift_off;
+            tp.row_slot = e->itab.p + e->NS + 1;
+            tp.total_frames = pl->total_frames;
+            tp.stride = kp.lp_stride; tp.D = kp.D; tp.lporder = kp.lporder; tp.ncep = kp.ncep; tp.is_lpa = kp.lp_is_lpa;
+            tp.lifter_on = kp.lifter_on; tp.e_mode = kp.e_mode; tp.e_slot = kp.e_slot;
+            tp.inv_stride = (unsigned)((1ull << 32) / (unsigned)tp.stride) + 1u;
+            tp.inv_D = (unsigned)((1ull << 32) / (unsigned)tp.D) + 1u;
+            const dim3 tg((unsigned)std::max<int64_t>(1, std::min<int64_t>((pl->total_frames + 255) / 256, (int64_t)e->n_cu * 8)));
+            const size_t tshm = (size_t)256 * ((tp.stride | 1) * (e->feat == FEAT_LPD ? 8 : 4) + (tp.D | 1) * 4);
+            if (e->feat == FEAT_LPD) hipLaunchKernelGGL((lp_tail_kernel<double, 0>), tg, dim3(256), tshm, s, tp);
+            else if (kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) hipLaunchKernelGGL((lp_tail_kernel<float, 12>), tg, dim3(256), tshm, s, tp);
+            else hipLaunchKernelGGL((lp_tail_kernel<float, 0>), tg, dim3(256), tshm, s, tp);
+            HIP_TRY(hipGetLastError());
+        }
         if (e->do_vad) {
             if (e->vp.cri == 1 && !e->vf) {
                 const dim3 g((unsigned)std::min<int64_t>((pl->total_frames + 3) / 4, (int64_t)e->n_cu * 4));
@@ -1479,9 +1515,15 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                                    pl->utt_info.p, pl->trap_chunks.p, cp);
             HIP_TRY(hipGetLastError());
         }
+        if (e->do_vad && e->vf && pl->n_live > 0) {
+            // the fused path left the Burg cepstra of every frame behind: the detector's recurrences, one utterance per lane
+            hipLaunchKernelGGL((vad_lanes_kernel<VF_NC>), dim3((pl->n_live + 63) / 64), dim3(64), 0, s, pl->vad_cf.p, pl->vf_order.p, pl->n_live,
+                               pl->d_row_off.p, d_vad, e->vp);
+            HIP_TRY(hipGetLastError());
+        }
         if (e->do_vad && !e->vf) {
             // After the post passes: the `fea` criterion reads the vector the writer sees (CMS applied), and the energy
-            // column is shifted in the finished rows.  The fused path replays the decisions in the wave that walks the utterance.
+            // column is shifted in the finished rows.
             hipLaunchKernelGGL(vad_decide_kernel, dim3(pl->n_utt), dim3(64), 0, s, pl->vad_ci.p, pl->pnr.p, d_rows,
                                pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
             HIP_TRY(hipGetLastError());

@@ -144,8 +144,6 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS)) void frontend_
         return c;
     };
 
-    VadRun vrun;  // VF: the VAD's recurrences along the wave's utterance
-    if constexpr (VF) vad_run_reset(vrun);
     CepDetRun sdet;            // SS: the cepstral detector's recurrences along the wave's utterance
     float snavg[NJ], snrav[NJ];  // SS: noise estimate(s), lane = bin
 #pragma unroll
@@ -1024,61 +1022,21 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS)) void frontend_
                         }
                     }
                 } else {
-                    // c[k] = R[k], the autocorrelation by cosine iDFT (src/fea/fea_impl.cc:181-198); every lane of the
-                    // frame runs Levinson-Durbin (src/fea/fea_impl.cc:200-222; the reference's aa[] copy is
-                    // replaced by the in-place symmetric update, same operations), then a -> c (251-284)
-                    // fp32: with the cube-root band energies the autocorrelation matrix is well
-                    // conditioned; measured deviation from a double recursion ~1e-6 (tests/test_gpu_parity.py::test_c3_plp)
+                    // c[k] = R[k], the autocorrelation by cosine iDFT (src/fea/fea_impl.cc:181-198), the same in the eight lanes
+                    // of a frame.  Levinson-Durbin and a -> c are one short sequential recursion per FRAME: run here, eight lanes
+                    // would repeat it for each of the step's eight frames.  The lags go to a scratch row instead (lane g stores
+                    // lags g, g + 8, g + 16) and lp_tail_kernel finishes 64 frames per wave, one per lane (lp_tail_kernel.h).
                     constexpr int PM = LPO ? LPO : MAX_LP;
-                    const int P_ = LPO ? LPO : p.lporder, ncep_ = LPO ? LPO : p.ncep;
-                    lp_t a[PM + 1], cc[PM + 1];
-                    const lp_t r0 = c[0];
-                    if (o_e_mode == 2 && fvalid && g == 0) orow[p.e_slot] = LPD ? (float)log((double)r0) : __builtin_amdgcn_logf((float)r0) * 0.69314718056f;  // E = ln R[0] (src/fea/fea_impl.cc:177)
-                    lp_t rc = -c[1] / r0;
-                    lp_t err = r0 * (1 - rc * rc);
-                    a[0] = 1;
-                    a[1] = rc;
+                    const int P_ = LPO ? LPO : p.lporder;
+                    lp_t *rrow = reinterpret_cast<lp_t *>(p.lp_r) + (rbase + fslot) * p.lp_stride;
 #pragma unroll
-                    for (int ik = 2; ik <= PM; ik++) {
-                        if (ik <= P_ && ik < NC) {  // the host picks NC > lporder
-                            lp_t dm = c[ik < NC ? ik : NC - 1];
+                    for (int h = 0; h < (PM + 8) / 8; h++) {
+                        if (h * 8 <= P_ && h * 8 < NC) {
+                            lp_t val = c[h * 8];
 #pragma unroll
-                            for (int n = 1; n < ik; n++) dm += a[n] * c[ik - n];
-                            rc = -dm / err;
-#pragma unroll
-                            for (int n = 1; n <= ik / 2; n++) {
-                                const lp_t lo = a[n], hi = a[ik - n];
-                                a[n] = lo + rc * hi;
-                                if (n != ik - n) a[ik - n] = hi + rc * lo;
-                            }
-                            a[ik] = rc;
-                            err *= (1 - rc * rc);
-                        }
-                    }
-                    if (p.lp_is_lpa) {
-#pragma unroll
-                        for (int i = 1; i <= PM; i++)
-                            if (i <= P_ && fvalid && g == (i & 7)) orow[i - 1] = (float)a[i];
-                    } else {
-                        cc[0] = LPD ? (lp_t)log((double)err) : (lp_t)(__builtin_amdgcn_logf((float)err) * 0.69314718056f);
-#pragma unroll
-                        for (int n = 1; n <= PM; n++) {
-                            if (n <= ncep_) {
-                                lp_t sum = 0;
-#pragma unroll
-                                for (int k = 1; k < n; k++)
-                                    if (k <= P_) sum += (lp_t)(n - k) * cc[n - k] * a[k];
-                                cc[n] = (n <= P_ ? -a[n] : (lp_t)0) - sum / (lp_t)n;
-                            }
-                        }
-#pragma unroll
-                        for (int n = 0; n <= PM; n++) {
-                            if (n <= ncep_) {
-                                float val = (float)cc[n];
-                                if (n >= 1 && p.lifter_on) val = (float)(cc[n] * (lp_t)ftab[p.lift_off + n - 1]);
-                                const int slot = row_slot[n];
-                                if (slot >= 0 && fvalid && g == (n & 7)) orow[slot] = val;
-                            }
+                            for (int j = 1; j < 8; j++)
+                                if (h * 8 + j < NC) val = (g == j) ? c[h * 8 + j] : val;
+                            if (fvalid && h * 8 + g <= P_) rrow[h * 8 + g] = val;
                         }
                     }
                 }
@@ -1090,24 +1048,14 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS)) void frontend_
             if (nv > 0) {
                 float mine_ab[2];
                 rebuild_cepstra(std::integral_constant<int, VF_NC>{}, std::false_type{}, mine_ab);
-                // decision replay of the step's frames, in order (vad_kernels.h): lane i takes coefficient i of frame s
-                if (rec.t0 == 0 && slot0 == 0) vad_run_reset(vrun);
-                uint8_t *vout = p.vad_out + (rbase - rec.t0);
-                // the coefficients of the next frame are fetched across the lanes while this frame's decision is worked out
-                // frame slot s: group s / 2, frame s % 2 of it (256-point mode); group s % 4 of half s / 4 (512-point mode)
-                float ca = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 15) << 2, __float_as_int(mine_ab[0])));
-                float cb = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 15) << 2, __float_as_int(mine_ab[1])));
-                for (int s_ = 0; s_ < nv; s_++) {
-                    const double cil = lane < VF_NC ? (double)((MODE == 1 ? (s_ & 1) : (s_ >> 2)) ? cb : ca) : 0.0;
-                    const int sn = (s_ + 1) & 7;
-                    const int srcn = ((16 * (MODE == 1 ? (sn >> 1) : (sn & 3)) + (lane & 15)) << 2);
-                    const float nca = __int_as_float(__builtin_amdgcn_ds_bpermute(srcn, __float_as_int(mine_ab[0])));
-                    const float ncb = __int_as_float(__builtin_amdgcn_ds_bpermute(srcn, __float_as_int(mine_ab[1])));
-                    vad_frame(vrun, p.vad, rec.t0 + slot0 + s_, 0.0, cil, lane, vout);
-                    ca = nca;
-                    cb = ncb;
+                // the cepstra go to the scratch rows of their frames; vad_lanes_kernel replays the detector's recurrences with one
+                // utterance per lane (vad_kernels.h).  256-point mode: mine_ab[x] of lane 16 fg + i = coefficient i of frame slot
+                // 2 fg + x; 512-point mode: of frame slot 4 x + fg.
+#pragma unroll
+                for (int x = 0; x < 2; x++) {
+                    const int sl = MODE == 1 ? 2 * fg + x : 4 * x + fg;
+                    if (sl < nv && l16 < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + l16] = mine_ab[x];
                 }
-                if (rec.t0 + slot0 + nv == rec.T) vad_flush(vrun, p.vad, rec.T, lane, vout);
                 STAMP(13);  // VF: decision replay of the step's frames
             }
         }

@@ -91,8 +91,9 @@ struct KParams {
     const int *tile_utt;
     float *ybuf;      // SY instantiations: time-domain frames [total_frames][window] ahead of the overlap-add
     float syn_scale;  // SY: 1 / wfft (sigOUT's amplitude factor, src/io/out.cc:416-422)
-    uint8_t *vad_out; // VF instantiations: the VAD bytes ('0' / '1' per frame), written by the wave that walks the utterance
-    VadParams vad;    // VF instantiations: the decision replay's parameters
+    float *vad_cf;    // VF instantiations: Burg cepstra of every frame [total_frames][VFC_STRIDE] for vad_lanes_kernel
+    void *lp_r;       // LP kinds: autocorrelation lags of every frame [total_frames][lp_stride] (float; double for FEAT_LPD), finished by lp_tail_kernel
+    int lp_stride;
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
 

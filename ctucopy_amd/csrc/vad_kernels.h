@@ -300,6 +300,139 @@ __device__ __forceinline__ void vad_flush(VadRun &r, const VadParams &vp, int T,
     }
 }
 
+// The same recurrences with one UTTERANCE PER LANE, for the fused Burg-cepstral path (vad_fused.h): the front end leaves
+// the cepstra of every frame in a scratch row (VFC_STRIDE floats) and a wave of this kernel walks 64 utterances at once.
+// Inside the front end the replay ran eight strictly sequential frames per wave step with all 64 lanes doing one
+// utterance's scalar work - a quarter of that kernel (profiles/r02_c4_vf_stamps.txt); here every lane carries its own
+// utterance, and the launch lasts as long as its longest one.  The distance is summed over the coefficients in order, as
+// the reference does (src/vad/vad.cc:239-247); everything else is vad_frame / vad_flush statement for statement.
+constexpr int VFC_STRIDE = 16;  // floats per frame in the cepstra scratch: the fused path's 14 coefficients, 64-byte rows
+
+template <int NCL>
+__global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__ cf, const int *__restrict__ order, int n_live,
+                                                        const int64_t *__restrict__ row_off, uint8_t *__restrict__ vad_out, VadParams vp) {
+    const int gidx = blockIdx.x * 64 + threadIdx.x;
+    const bool live = gidx < n_live;
+    const int u = live ? order[gidx] : 0;
+    const int64_t r0 = live ? row_off[u] : 0;
+    const int T = live ? (int)(row_off[u + 1] - r0) : 0;
+    int Tmax = T;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, off, 64));
+    const int order_f = vp.filter_order, h = (order_f - 1) / 2;
+    double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
+    double c0[NCL];
+#pragma unroll
+    for (int i = 0; i < NCL; i++) c0[i] = 0.0;
+    int adapt_vad = 0, hidx = 0, nout = 0, nsum = 0;
+    unsigned long long hist = 0;
+    uint8_t *out = vad_out + r0;
+    auto push = [&](int v) {
+        const int old = (int)((hist >> hidx) & 1ull);
+        hist = (hist & ~(1ull << hidx)) | ((unsigned long long)v << hidx);
+        nsum += v - old;
+        hidx = (hidx + 1 == order_f) ? 0 : hidx + 1;
+    };
+    constexpr int AHEAD = 4;  // frames whose cepstra are in flight while the current ones are worked on (one wave per SIMD: no other cover)
+    float4 q[AHEAD][NCL / 4 + (NCL % 4 ? 1 : 0)];
+    constexpr int NQ = NCL / 4 + (NCL % 4 ? 1 : 0);
+    auto fetch = [&](int slot, int t) {
+        const float4 *src = reinterpret_cast<const float4 *>(cf + (r0 + (t < T ? t : 0)) * VFC_STRIDE);
+#pragma unroll
+        for (int j = 0; j < NQ; j++) q[slot][j] = (t < T) ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+#pragma unroll
+    for (int a = 0; a < AHEAD; a++) fetch(a, a);
+    for (int tb = 0; tb < Tmax; tb += AHEAD) {
+#pragma unroll
+        for (int a = 0; a < AHEAD; a++) {
+            const int t = tb + a;
+            double ci[NCL];
+#pragma unroll
+            for (int i = 0; i < NCL; i++) {
+                const float4 v = q[a][i >> 2];
+                ci[i] = (double)((i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w);
+            }
+            fetch(a, t + AHEAD);
+            if (t < T) {
+                double cri;
+                if (t == 0) {
+#pragma unroll
+                    for (int i = 0; i < NCL; i++) c0[i] = ci[i];
+                    cri = 0.0;
+                } else {
+                    if (t == 1) {
+#pragma unroll
+                        for (int i = 0; i < NCL; i++) c0[i] = (c0[i] + ci[i]) / 2.0;
+                    }
+                    double sum = 0.0;  // c0 itself is not part of the distance
+#pragma unroll
+                    for (int i = 1; i < NCL; i++) {
+                        const double dl = ci[i] - c0[i];
+                        sum += dl * dl;
+                    }
+                    cri = 4.3429 * sqrt(2 * sum);
+                }
+                int vad0;
+                if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
+                else if (vp.thr == 1) {
+                    if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
+                    else {
+                        crimin = cri < crimin ? cri : crimin;
+                        crimax = cri > crimax ? cri : crimax;
+                    }
+                    vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
+                } else if (vp.thr == 2) {
+                    if (t == 0) {
+                        crimean = cri;
+                        crimean2 = cri * cri;
+                        crivar = 0.0;
+                        adapt_vad = 0;
+                    } else {
+                        const double thr = crimean + vp.adapt_za * sqrt(crivar);
+                        if (cri < thr || t <= vp.adapt_init) {
+                            crimean = vp.adapt_q * crimean + (1.0 - vp.adapt_q) * cri;
+                            crimean2 = vp.adapt_q * crimean2 + (1.0 - vp.adapt_q) * cri * cri;
+                            crivar = crimean2 - crimean * crimean;
+                            adapt_vad = 0;
+                        } else adapt_vad = 1;
+                    }
+                    vad0 = adapt_vad;
+                } else {
+                    const int init = vp.dyn_init > 1 ? vp.dyn_init : 1;
+                    if (t < init) {
+                        dmax = dmin = cri;
+                        vad0 = 0;
+                    } else if (t == init) {
+                        dmax = (cri > dmax ? cri : dmax) + vp.dyn_min / 10.0;
+                        dmin = (cri < dmin ? cri : dmin) - vp.dyn_min / 10.0;
+                        vad0 = 0;
+                    } else {
+                        dmax = dmax < cri ? vp.qmaxinc * dmax + (1.0 - vp.qmaxinc) * cri : vp.qmaxdec * dmax + (1.0 - vp.qmaxdec) * cri;
+                        dmin = dmin > cri ? vp.qmindec * dmin + (1.0 - vp.qmindec) * cri : vp.qmininc * dmin + (1.0 - vp.qmininc) * cri;
+                        const double dyn = dmax - dmin;
+                        vad0 = (cri > dmin + (vp.dyn_perc / 100.0) * dyn) && (dyn > vp.dyn_min);
+                    }
+                }
+                if (!(vad0 && t > vp.cep_init)) {  // background update (src/vad/vad.cc:288-294)
+#pragma unroll
+                    for (int i = 0; i < NCL; i++) c0[i] = vp.cep_p * c0[i] + (1.0 - vp.cep_p) * ci[i];
+                }
+                push(vad0);
+                if (t >= h) {
+                    out[nout] = (2 * nsum >= order_f) ? '1' : '0';
+                    nout++;
+                }
+            }
+        }
+    }
+    for (int k = 0; k < h && nout < T; k++) {  // end of the utterance: zeros until every frame has its byte (src/vad/vad.h:156-175)
+        push(0);
+        out[nout] = (2 * nsum >= order_f) ? '1' : '0';
+        nout++;
+    }
+}
+
 // One wave per utterance: stages 64 frames of criterion inputs in LDS with coalesced loads, then replays them.
 __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict__ ci_all, const float *__restrict__ cri_energy,
                                                          float *__restrict__ rows, const int64_t *__restrict__ row_off,
