@@ -21,6 +21,7 @@ struct BigParams {
     const float *fbw;        // the bands' non-zero runs one after the other (fb_total floats)
     const int *fb_range;     // [B][3] first / last non-zero bin, offset of the run in fbw
     int fb_total;
+    const int *seg;          // wave1k_kernel: the bank cut into <= 64 segments, [64][4] {band, first bin, bins, offset into fbw} | [B][2] {first segment, segments}
     const float *coef;       // dctc: [ncoef_out][B] rows in writer order (norm and lifter folded in); lp: [lporder+1][B] as doubles below
     const double *coef_d;    // lp: cosine iDFT rows in double [lporder+1][B]
     const float *lifter;     // [ncep]

@@ -39,6 +39,7 @@
 #include "decode_kernels.h"
 #include "bigfft_kernel.h"
 #include "lp_tail_kernel.h"
+#include "wave1k_kernel.h"
 
 namespace {
 
@@ -98,10 +99,11 @@ struct ctu_engine {
     DevBuf<int> itab;
     // FFT sizes of 1024 to 4096 points (bigfft_kernel.h)
     bool big = false;
+    bool wave1k = false;        // 1024-point frames on wave1k_kernel (one wave per frame); CTU_WAVE1K=0 keeps them on bigfft_kernel
     int big_fb_total = 0;
     DevBuf<float> big_win, big_fbw, big_coef, big_lifter;
     DevBuf<float2> big_tw;
-    DevBuf<int> big_range, big_slot;
+    DevBuf<int> big_range, big_slot, big_seg;
     DevBuf<double> big_coef_d;
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, cfd_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
@@ -266,7 +268,7 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.window < 32) return "window shorter than 32 samples";
     if (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) {
         if (o.fea_lporder >= d.B) return "LP order not below the number of bands: the normal equations are singular and the reference's output is rounding noise";
-        if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above the in-register limit";
+        if (o.fea_lporder > MAX_LP || o.fea_ncepcoefs > MAX_LP) return "LP order / cepstral order above 23 (the front end accumulates 24 lags per frame)";
     }
     if (d.kind == ctu::FeaKind::Dctc && d.nfea > MAXC) return "more cepstral coefficients than the kernel accumulates";
     if (d.B > 512) return "more than 512 filter bank channels";
@@ -618,6 +620,32 @@ void build_big_tables(ctu_engine *e) {
     if (fbw.empty()) fbw.push_back(0.f);
     e->big_fbw.upload(fbw);
     e->big_range.upload(range);
+    {
+        // wave1k_kernel's bank: the bands' bin runs cut into at most 64 segments of at most S bins (the smallest S that fits)
+        std::vector<int> seg(256 + 2 * (size_t)std::max(d.B, 1), 0);
+        if (d.B <= 64) {
+            int S = 1;
+            for (;; S++) {
+                int n = 0;
+                for (int b = 0; b < d.B; b++) n += std::max(1, (d.fb_last[b] - d.fb_first[b] + 1 + S - 1) / S);
+                if (n <= 64) break;
+            }
+            int lane = 0;
+            for (int b = 0; b < d.B; b++) {
+                const int w = d.fb_last[b] - d.fb_first[b] + 1, ns = std::max(1, (w + S - 1) / S);
+                seg[256 + 2 * b] = lane;
+                seg[256 + 2 * b + 1] = ns;
+                for (int i = 0; i < ns; i++, lane++) {
+                    const int k0 = d.fb_first[b] + i * S, cnt = std::max(0, std::min(S, w - i * S));
+                    seg[4 * lane] = b;
+                    seg[4 * lane + 1] = k0;
+                    seg[4 * lane + 2] = cnt;
+                    seg[4 * lane + 3] = range[3 * b + 2] + i * S;
+                }
+            }
+        }
+        e->big_seg.upload(seg);
+    }
     e->ncoef_out = 0;
     std::vector<float> coef(4, 0.f);
     std::vector<double> coef_d(4, 0.0);
@@ -675,6 +703,7 @@ void build_tables(ctu_engine *e) {
     const double pi = 3.14159265358979323846;
     e->big = d.wfft >= 1024;
     if (e->big) {
+        e->wave1k = d.wfft == 1024 && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
         build_big_tables(e);
         return;
     }
@@ -1185,8 +1214,8 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             pl->trap_chunks128.upload(c128);
         }
         if (d.kind == ctu::FeaKind::TrapDct) pl->logmel.alloc((size_t)ro * d.B);
-        if ((d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) && !e->big)
-            pl->lp_r.alloc(((size_t)std::max<int64_t>(ro, 1) * (d.o.fea_lporder + 1) * (e->feat == FEAT_LPD ? 8 : 4) + 7) / 8);
+        if ((d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) && (!e->big || e->wave1k))
+            pl->lp_r.alloc(((size_t)std::max<int64_t>(ro, 1) * (d.o.fea_lporder + 1) * ((e->feat == FEAT_LPD || e->big) ? 8 : 4) + 7) / 8);
         if (d.post_order > 0 || d.cms) pl->base_rows.alloc((size_t)ro * d.Dbase);
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
@@ -1326,6 +1355,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             bp.band_to_scratch = kp.band_to_scratch; bp.lp_is_lpa = kp.lp_is_lpa; bp.lporder = kp.lporder; bp.ncep = kp.ncep;
             bp.lifter_on = kp.lifter_on; bp.preem = kp.preem;
             bp.fb_total = e->big_fb_total;
+            bp.seg = e->big_seg.p;
             const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8 + (size_t)d.wfft / 2 * 8 +
                                (size_t)((d.window + 3) & ~3) * 4 + (size_t)((e->big_fb_total + 3) & ~3) * 4 +
                                (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
@@ -1338,7 +1368,22 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             }
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shm));
             const int g = std::max(1, std::min(pl->n_tiles, e->n_cu * per_cu));
-            if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);
+            if (e->wave1k) {
+                // 1024 points: one wave per frame, the transform in registers (wave1k_kernel.h); tiles are dealt to waves
+                const size_t wshm = ((size_t)4 * W1K_WAVE_FLOATS + 1024 + (size_t)((e->big_fb_total + 3) & ~3) + 2) * 4 +
+                                    (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
+                                    (size_t)(((e->feat == FEAT_DCTC ? e->ncoef_out * d.B : 0) + 3) & ~3) * 4 + (size_t)((3 * d.B + 3) & ~3) * 4 + (size_t)(256 + 2 * d.B) * 4 + 64;
+                if (wshm > 160 * 1024) throw std::runtime_error("filter bank too wide for the LDS tables of the 1024-point kernel");
+                const void *wfn = (const void *)wave1k_kernel;
+                if (wshm > 64 * 1024 && !e->attr_done.count(wfn)) {
+                    HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    e->attr_done.insert(wfn);
+                }
+                const int wper_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / wshm));
+                const int wg = std::max(1, std::min((pl->n_tiles + 3) / 4, e->n_cu * wper_cu));
+                hipLaunchKernelGGL(wave1k_kernel, dim3(wg), dim3(256), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
+            }
+            else if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);
             else if (d.wfft == 2048) hipLaunchKernelGGL(bigfft_kernel<8>, dim3(g), dim3(256), shm, s, bp);
             else hipLaunchKernelGGL(bigfft_kernel<16>, dim3(g), dim3(256), shm, s, bp);
         }
@@ -1412,20 +1457,20 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             }
         }
 #endif
-        if ((e->feat == FEAT_LP || e->feat == FEAT_LPD) && !e->big && !signal) {
+        if ((e->feat == FEAT_LP || e->feat == FEAT_LPD) && (!e->big || e->wave1k) && !signal) {
             LpTailParams tp;
             tp.lags = pl->lp_r.p;
             tp.rows = kp.rows;
-            tp.lifter = e->ftab.p + e->lift_off;
-            tp.row_slot = e->itab.p + e->NS + 1;
+            tp.lifter = e->big ? e->big_lifter.p : e->ftab.p + e->lift_off;
+            tp.row_slot = e->big ? e->big_slot.p : e->itab.p + e->NS + 1;
             tp.total_frames = pl->total_frames;
             tp.stride = kp.lp_stride; tp.D = kp.D; tp.lporder = kp.lporder; tp.ncep = kp.ncep; tp.is_lpa = kp.lp_is_lpa;
             tp.lifter_on = kp.lifter_on; tp.e_mode = kp.e_mode; tp.e_slot = kp.e_slot;
             tp.inv_stride = (unsigned)((1ull << 32) / (unsigned)tp.stride) + 1u;
             tp.inv_D = (unsigned)((1ull << 32) / (unsigned)tp.D) + 1u;
             const dim3 tg((unsigned)std::max<int64_t>(1, std::min<int64_t>((pl->total_frames + 255) / 256, (int64_t)e->n_cu * 8)));
-            const size_t tshm = (size_t)256 * ((tp.stride | 1) * (e->feat == FEAT_LPD ? 8 : 4) + (tp.D | 1) * 4);
-            if (e->feat == FEAT_LPD) hipLaunchKernelGGL((lp_tail_kernel<double, 0>), tg, dim3(256), tshm, s, tp);
+            const size_t tshm = (size_t)256 * ((tp.stride | 1) * ((e->feat == FEAT_LPD || e->big) ? 8 : 4) + (tp.D | 1) * 4);
+            if (e->feat == FEAT_LPD || e->big) hipLaunchKernelGGL((lp_tail_kernel<double, 0>), tg, dim3(256), tshm, s, tp);
             else if (kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) hipLaunchKernelGGL((lp_tail_kernel<float, 12>), tg, dim3(256), tshm, s, tp);
             else hipLaunchKernelGGL((lp_tail_kernel<float, 0>), tg, dim3(256), tshm, s, tp);
             HIP_TRY(hipGetLastError());
@@ -1926,7 +1971,8 @@ const char *ctu_engine_kernel_name(const ctu_engine *e) {
         const ctu::Design &d = *e->design;
         const ctu::Opts &o = d.o;
         std::string n;
-        if (e->big) n = "bigfft_kernel<" + std::to_string(d.wfft / 256) + ">";
+        if (e->wave1k) n = "wave1k_kernel";
+        else if (e->big) n = "bigfft_kernel<" + std::to_string(d.wfft / 256) + ">";
         else {
             const char *feat = e->feat == FEAT_DCTC ? "DCTC" : e->feat == FEAT_BANDS ? "BANDS" : e->feat == FEAT_LP ? "LP" : "LPD";
             const bool exten = o.nr_mode == "exten" && !o.nr_when_afterFB;

@@ -9,7 +9,7 @@ constexpr int WG = 512;        // threads per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
 constexpr int PSTRIDE = 260;   // floats per P-tile row: 257 bins padded so rows stay 16-byte aligned (b128 reads in phase 2)
 constexpr int LDS_2WG = 80 * 1024;  // two workgroups per CU fit when a workgroup's LDS stays at or under this
-constexpr int MAX_LP = 16;     // Levinson order limit of the in-register recursion
+constexpr int MAX_LP = 23;     // LP order / cepstral order limit: the front end accumulates MAXC = 24 lags (R[0..23]) per frame, lp_tail_kernel keeps one frame's recursion in a lane's registers
 constexpr int GEN_PLAIN = 0, GEN_INLD = 1, GEN_EXTEN = 2, GEN_FULL = 3, GEN_DC1 = 4;  // front-end option specialisations (frontend_kernel.h)
 constexpr int MAXC = 24;       // most coefficients accumulated per frame in phase 2 (cepstra incl. c0, or LP lags)
 constexpr int PCM_ALIGN = 8;   // utterance starts are multiples of this many samples

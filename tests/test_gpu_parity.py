@@ -127,6 +127,16 @@ def test_c3_plp(Engine):
     _check(Engine, C3 + ["-fea_ncepcoefs", "16", "-fea_lporder", "10"], [synth_utt(43, 16000)])
 
 
+def test_lp_orders_up_to_23(Engine):
+    # lp_tail_kernel keeps one frame's Levinson-Durbin / a -> c recursion in a lane: orders and cepstral counts up to 23 (24 lags)
+    mel = "-fs 16000 -format_in raw -format_out htk -preem 0.97 -fb_scale mel -fb_shape triang -fb_norm off -fb_power on -fb_eqld on -fb_inld on -fb_definition 30filters".split()
+    utts = [synth_utt(48, 20000), sig("CS0")[:24000]]
+    _check(Engine, mel + "-fea_kind lpc -fea_lporder 20 -fea_ncepcoefs 22".split(), utts)
+    _check(Engine, mel + "-fea_kind lpc -fea_lporder 23 -fea_ncepcoefs 23 -fea_E on".split(), utts)
+    _check(Engine, mel + "-fea_kind lpa -fea_lporder 18 -fea_ncepcoefs 18".split(), utts[:1])
+    _check(Engine, mel + "-fb_inld off -fea_kind lpc -fea_lporder 17 -fea_ncepcoefs 17".split(), utts[:1])
+
+
 def test_lp_on_uncompressed_bands(Engine):
     # LP analysis without -fb_inld (src/fea/fea_impl.cc:165-169 squares the band energies): the autocorrelation and the
     # recursions run in double on the device (FEAT_LPD); PLP's filter bank with the law switched off, a mel bank, lpa, 8 kHz
