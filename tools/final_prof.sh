@@ -9,8 +9,8 @@ mkdir -p $O
 cd $R
 python3 bench.py > $O/bench_full.json 2> $O/bench_full.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu > $O/trace.log 2>&1
-P="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu --no-extra > $O/trace.log 2>&1
+P="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extra"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $O/pmc1 -- $P > $O/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $O/pmc2 -- $P > $O/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc3 -- $P > $O/pmc3.log 2>&1
