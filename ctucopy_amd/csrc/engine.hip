@@ -1114,7 +1114,10 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     // Each workgroup walks a chain of tiles.  Stateless chains stride over the tile list; with a
     // per-utterance recurrence (exten) a workgroup takes whole utterances, tile after tile.
     std::vector<int> wg_first;
-    const int max_wg = e->n_cu * ((CTU_LB >= 4 && e->lds_bytes <= (size_t)LDS_2WG) ? 2 : 1);
+    // workgroups that fit a CU at once: two when the instantiation keeps to 128 VGPRs and 80 KB of LDS; the synthesis and the
+    // 512-point detector instantiations take 256 VGPRs (fe_waves_per_simd)
+    const bool wide_regs = (e->sy && CTU_SY_LB < 4) || ((e->vf || e->ss) && (!e->mode || CTU_VF1_LB < 4));
+    const int max_wg = e->n_cu * ((CTU_LB >= 4 && e->lds_bytes <= (size_t)LDS_2WG && !wide_regs) ? 2 : 1);
     if (e->per_wave) {
         // chains per wave: whole utterances, longest first onto the least loaded chain (LPT), tile after tile
         std::vector<int> live;  // utterances that have at least one frame
@@ -1370,7 +1373,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const int g = std::max(1, std::min(pl->n_tiles, e->n_cu * per_cu));
             if (e->wave1k) {
                 // 1024 points: one wave per frame, the transform in registers (wave1k_kernel.h); tiles are dealt to waves
-                const size_t wshm = ((size_t)4 * W1K_WAVE_FLOATS + 1024 + (size_t)((e->big_fb_total + 3) & ~3) + 2) * 4 +
+                const size_t wshm = ((size_t)W1K_WAVES * W1K_WAVE_FLOATS + 1024 + 2048 + (size_t)((e->big_fb_total + 3) & ~3) + 2) * 4 +
                                     (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
                                     (size_t)(((e->feat == FEAT_DCTC ? e->ncoef_out * d.B : 0) + 3) & ~3) * 4 + (size_t)((3 * d.B + 3) & ~3) * 4 + (size_t)(256 + 2 * d.B) * 4 + 64;
                 if (wshm > 160 * 1024) throw std::runtime_error("filter bank too wide for the LDS tables of the 1024-point kernel");
@@ -1379,9 +1382,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                     HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     e->attr_done.insert(wfn);
                 }
-                const int wper_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / wshm));
-                const int wg = std::max(1, std::min((pl->n_tiles + 3) / 4, e->n_cu * wper_cu));
-                hipLaunchKernelGGL(wave1k_kernel, dim3(wg), dim3(256), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
+                const int wper_cu = (int)std::max<size_t>(1, std::min<size_t>(CTU_W1K_LB * 4 / W1K_WAVES, (160 * 1024) / wshm));
+                const int wg = std::max(1, std::min((pl->n_tiles + W1K_WAVES - 1) / W1K_WAVES, e->n_cu * wper_cu));
+                hipLaunchKernelGGL(wave1k_kernel, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
             }
             else if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);
             else if (d.wfft == 2048) hipLaunchKernelGGL(bigfft_kernel<8>, dim3(g), dim3(256), shm, s, bp);

@@ -66,10 +66,18 @@ namespace {
 //         the overlap-add kernel; no spectra through HBM, no phase 2.
 // The fused detector paths of the 512-point mode (VF / SS with MODE 0) keep both passes' transform outputs and a 25-sample
 // lattice per lane alive: 256 VGPRs, one workgroup per CU (their staging area takes the LDS of the second one anyway).
-constexpr int fe_waves_per_simd(int mode, bool vf, bool ss) { return ((vf || ss) && mode == 0) ? 2 : CTU_LB; }
+#ifndef CTU_SY_LB
+#define CTU_SY_LB 2  // register budget of the synthesis instantiations (SY): 256 VGPRs, one workgroup per CU.  Measured (profiles/r03_ab_sy_register_budget.txt): at 128 VGPRs they spill 200 bytes per lane; 2 -> -25 % kernel time, 3 -> -21 %
+#endif
+#ifndef CTU_VF1_LB
+#define CTU_VF1_LB CTU_LB  // experiment: register budget of the fused-detector instantiations of the 256-point mode
+#endif
+constexpr int fe_waves_per_simd(int mode, bool vf, bool ss, bool sy = false) {
+    return ((vf || ss) && mode == 0) ? 2 : (sy ? CTU_SY_LB : ((vf || ss) ? CTU_VF1_LB : CTU_LB));
+}
 
 template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false, bool SY = false>
-__global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS)) void frontend_kernel(const KParams p) {
+__global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
     static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
     static_assert(!VF || !VX, "VF: no spectrum export");
@@ -112,6 +120,14 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS)) void frontend_
 #if CTU_STAMP
     unsigned long long st_acc[16] = {0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+#ifdef CTU_PRIO  // experiment: static priority for the later-dispatched half of the workgroup (waves 4-7)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(CTU_PRIO);
+#endif
+#ifdef CTU_STAGGER  // experiment: half of the waves start late, so that partners on a SIMD sit in different phases of a step
+    if (CTU_STAGGER_SEL) {
+        for (int i = 0; i < CTU_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
 #endif
     int tile = as_const(p.wg_first)[per_wave ? blockIdx.x * NWAVE + wave : blockIdx.x];
     if (tile < 0) return;

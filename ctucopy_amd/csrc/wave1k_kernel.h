@@ -1,7 +1,7 @@
 // 1024-point frames (windows of 513 to 1024 samples - every window of 33 to 64 ms at 16 kHz, src/io/opts.cc:277-280) with the
 // transform in registers: ONE WAVE PER FRAME, no workgroup barrier anywhere.  The packed real FFT is a 512-point complex
 // FFT = 8 x 8 x 8: each lane holds 8 complex values, three in-register 8-point DFTs with two transposes through the wave's
-// own LDS area in between (conflict-free: row strides of 72 dwords), then the untangle with the mirror bin fetched across
+// own LDS plane in between (re, then im; conflict-free: row stride 72 dwords), then the untangle with the mirror bin fetched across
 // the wave by ds_bpermute.  The rest of the chain is bigfft_kernel's (the plain chain: pre-emphasis, window, mean removal,
 // |.|^2 or |.|, any filter bank of up to 64 bands, ^0.33, log, DCT / band outputs / LP lags, the energy column), at wave
 // granularity; LP kinds leave their autocorrelation lags to lp_tail_kernel.  Included by engine.hip.
@@ -58,50 +58,54 @@ __device__ __forceinline__ float wave_sum_f(float x) {
     return (lane_read(x, 0) + lane_read(x, 16)) + (lane_read(x, 32) + lane_read(x, 48));
 }
 
-constexpr int W1K_TS = 72;                       // dwords between the rows of a transpose plane
-constexpr int W1K_PLANE = 8 * W1K_TS;            // one plane (re or im) of a transpose
-constexpr int W1K_WAVE_FLOATS = 2 * W1K_PLANE + 516 + 64 + 64 + 64 + 8;  // planes | P[513 (+3)] | Y[64] | Ylog[64] | partial band sums [64] | slack
+constexpr int W1K_TS = 72;                       // dwords between the rows of the transpose plane
+constexpr int W1K_PLANE = 8 * W1K_TS;            // the plane: re and im of a transpose go through it one after the other; the power
+                                                 // spectrum P[513 (+3)] takes its place once the transform is done
+constexpr int W1K_WAVE_FLOATS = W1K_PLANE + 64 + 64 + 64;  // plane / P | Y[64] | Ylog[64] | partial band sums [64]
+#ifndef CTU_W1K_WAVES
+#define CTU_W1K_WAVES 4  // measured (profiles/r03_ab_wave1k_occupancy.txt, 1.78 M frames): 4 waves x 5 workgroups per CU (96 VGPRs) 2.86 ms,
+#define CTU_W1K_LB 5     // 8 x 3 (80 VGPRs, 35 spilled) 3.09 ms, 4 x 4 (120 VGPRs, none spilled) 3.05 ms; round 3's first version (163 VGPRs, 3 per SIMD) 4.10 ms
+#endif
+constexpr int W1K_WAVES = CTU_W1K_WAVES;         // waves per workgroup
 
-__global__ __launch_bounds__(256) void wave1k_kernel(const BigParams p, void *lp_r, int lp_stride) {
+// A frame is one wave's serial chain of ~40 LDS round trips: what hides them is other waves, so the kernel is built for five
+// per SIMD - twiddles come from one shared W1024 table instead of 48 registers per lane, samples are not fetched a frame ahead.
+__global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(const BigParams p, void *lp_r, int lp_stride) {
     extern __shared__ __align__(16) float smem[];
     constexpr int Nc = 512;
     const int K = p.K;  // 513
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // per-wave areas, then the tables shared by the workgroup's four waves
     float *wbase = smem + wave * W1K_WAVE_FLOATS;
-    float *xre = wbase, *xim = wbase + W1K_PLANE;
-    float *P = wbase + 2 * W1K_PLANE;
-    float *Y = P + 516, *Ylog = Y + 64, *part_s = Ylog + 64;
-    float *tab = smem + 4 * W1K_WAVE_FLOATS;
+    float *xpl = wbase;
+    float *P = wbase;
+    float *Y = wbase + W1K_PLANE, *Ylog = Y + 64, *part_s = Ylog + 64;
+    float *tab = smem + W1K_WAVES * W1K_WAVE_FLOATS;
     float2 *lwin2 = reinterpret_cast<float2 *>(tab);           // [512] (w[2n], w[2n+1]), zero beyond the window
-    float *lfb = tab + 1024;
+    float2 *ltw = reinterpret_cast<float2 *>(tab + 1024);      // [1024] W1024^m = e^{-2 pi i m / 1024}
+    float *lfb = tab + 1024 + 2048;
     double *lcoef_d = reinterpret_cast<double *>(lfb + ((p.fb_total + 3) & ~3) + (((p.fb_total + 3) & ~3) & 1));
     const int ncd = (p.feat == FEAT_LP) ? (p.lporder + 1) * p.B : 0, ncf = (p.feat == FEAT_DCTC) ? p.ncoef_out * p.B : 0;
     float *lcoef = reinterpret_cast<float *>(lcoef_d + ncd);
     int *lrange = reinterpret_cast<int *>(lcoef + ((ncf + 3) & ~3));  // [B][3] bands' bin ranges, then the bank's segment table
     int *lseg = lrange + ((3 * p.B + 3) & ~3);                        // [64][4] {band, first bin, bins, weight offset} | [B][2] {first lane, lanes}
-    for (int i = tid; i < 1024; i += 256) tab[i] = i < p.window ? p.win[i] : 0.f;
-    for (int i = tid; i < p.fb_total; i += 256) lfb[i] = p.fbw[i];
-    for (int i = tid; i < ncd; i += 256) lcoef_d[i] = p.coef_d[i];
-    for (int i = tid; i < ncf; i += 256) lcoef[i] = p.coef[i];
-    for (int i = tid; i < 3 * p.B; i += 256) lrange[i] = p.fb_range[i];
-    for (int i = tid; i < 256 + 2 * p.B; i += 256) lseg[i] = p.seg[i];
+    constexpr int NT_ = 64 * W1K_WAVES;
+    for (int i = tid; i < 1024; i += NT_) tab[i] = i < p.window ? p.win[i] : 0.f;
+    for (int i = tid; i < 1024; i += NT_) {  // p.tw holds m < 512: the other half is its negative
+        const float2 t = p.tw[i & 511];
+        ltw[i] = i & 512 ? make_float2(-t.x, -t.y) : t;
+    }
+    for (int i = tid; i < p.fb_total; i += NT_) lfb[i] = p.fbw[i];
+    for (int i = tid; i < ncd; i += NT_) lcoef_d[i] = p.coef_d[i];
+    for (int i = tid; i < ncf; i += NT_) lcoef[i] = p.coef[i];
+    for (int i = tid; i < 3 * p.B; i += NT_) lrange[i] = p.fb_range[i];
+    for (int i = tid; i < 256 + 2 * p.B; i += NT_) lseg[i] = p.seg[i];
     __syncthreads();  // the only workgroup barrier: tables are in place
 
-    // per-lane twiddles, kept in registers for the life of the kernel (p.tw[m] = e^{-2 pi i m / 1024}, m < 512)
-    auto w512 = [&](int j) {  // W512^j, any j >= 0
-        j &= 511;
-        const float2 t = p.tw[2 * (j & 255)];
-        return j & 256 ? make_float2(-t.x, -t.y) : t;
-    };
     const int d0 = lane & 7, d1 = lane >> 3;  // low / high digit of the lane number
-    float2 tw1[8], tw2[8], twu[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        tw1[r] = w512(8 * d1 * r);            // after step 1: lane (n0 = d0, n1 = d1), register k2 = r: W64^(n1 k2)
-        tw2[r] = w512(d0 * (d1 + 8 * r));     // after step 2: lane (n0 = d0, k2 = d1), register k1 = r: W512^(n0 (k2 + 8 k1))
-        twu[r] = p.tw[(lane + 64 * r) & 511]; // untangle: W1024^k of bin k = lane + 64 r
-    }
+    // twiddle indices into W1024 (W512^j = W1024^(2j)):  after step 1, lane (n0 = d0, n1 = d1), register k2 = r: W64^(n1 k2) = W1024^(16 n1 r);
+    // after step 2, lane (n0 = d0, k2 = d1), register k1 = r: W512^(n0 (k2 + 8 k1)) = W1024^(2 n0 k2 + 16 n0 r)
+    const int tw1_step = 16 * d1, tw2_base = 2 * d0 * d1, tw2_step = 16 * d0;
     const int mirror = ((64 - lane) & 63) << 2;
     // output slots of the DCT rows this lane's 16-lane group takes in round i (row 4 i + lane / 16): read once, not per frame
     int slot_of_round[8];
@@ -111,18 +115,16 @@ __global__ __launch_bounds__(256) void wave1k_kernel(const BigParams p, void *lp
         slot_of_round[i] = (p.feat == FEAT_DCTC && r < p.ncoef_out) ? p.row_slot[r] : -1;
     }
 
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int gw = blockIdx.x * W1K_WAVES + wave, nw = gridDim.x * W1K_WAVES;
     for (int tile = gw; tile < p.n_tiles; tile += nw) {
         const TileRec rec = load_rec(p.tiles, tile);
-        pcm4 q[8], qn[8];
-        auto fetch = [&](pcm4 (&dst)[8], int f) {  // samples x[i-2 .. i+1], i = 2 lane + 128 n2, of frame f
-            const int16_t *x = p.pcm + rec.sbase + (int64_t)f * p.wshift + 2 * lane - 2;
-#pragma unroll
-            for (int j = 0; j < 8; j++) dst[j] = *reinterpret_cast<const pcm4 *>(x + 128 * j);
-        };
-        fetch(q, 0);
         for (int f = 0; f < rec.nvalid; f++) {
-            if (f + 1 < rec.nvalid) fetch(qn, f + 1);
+            pcm4 q[8];  // samples x[i-2 .. i+1], i = 2 lane + 128 n2
+            {
+                const int16_t *x = p.pcm + rec.sbase + (int64_t)f * p.wshift + 2 * lane - 2;
+#pragma unroll
+                for (int j = 0; j < 8; j++) q[j] = *reinterpret_cast<const pcm4 *>(x + 128 * j);
+            }
             const bool file_start = lane == 0 && rec.t0 + f == 0;
             // ---- pre-emphasis x window (src/io/in.cc:364-372), z[n] = y[2n] + i y[2n+1], n = lane + 64 n2
             float2 v[8];
@@ -153,35 +155,33 @@ __global__ __launch_bounds__(256) void wave1k_kernel(const BigParams p, void *lp
                 }
             }
             // ---- 512-point complex FFT
+            auto exchange = [&](int wbase_, int wstep) {  // one transpose: every lane writes v[r] at wbase_ + wstep r and reads lane + 72 r
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 8; r++) xpl[wbase_ + wstep * r] = v[r].x;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 8; r++) v[r].x = xpl[lane + W1K_TS * r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 8; r++) xpl[wbase_ + wstep * r] = v[r].y;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 8; r++) v[r].y = xpl[lane + W1K_TS * r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            };
             dft8(v);
 #pragma unroll
-            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], tw1[r]);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 8; r++) {  // element (n0, n1, k2 = r) -> row n1, column n0 + 8 k2
-                xre[d0 + 8 * r + W1K_TS * d1] = v[r].x;
-                xim[d0 + 8 * r + W1K_TS * d1] = v[r].y;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = make_float2(xre[lane + W1K_TS * r], xim[lane + W1K_TS * r]);  // lane = n0 + 8 k2, register n1 = r
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], ltw[(tw1_step * r) & 1023]);
+            exchange(d0 + W1K_TS * d1, 8);      // element (n0, n1, k2 = r) -> row n1, column n0 + 8 k2; then lane = n0 + 8 k2, register n1
             dft8(v);
 #pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = cmul(v[r], tw2[r]);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {  // element (n0, k1 = r, k2) -> row n0, column k2 + 8 k1
-                xre[d1 + 8 * r + W1K_TS * d0] = v[r].x;
-                xim[d1 + 8 * r + W1K_TS * d0] = v[r].y;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = make_float2(xre[lane + W1K_TS * r], xim[lane + W1K_TS * r]);  // lane = k2 + 8 k1, register n0 = r
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 8; r++) v[r] = cmul(v[r], ltw[(tw2_base + tw2_step * r) & 1023]);
+            exchange(d1 + W1K_TS * d0, 8);      // element (n0, k1 = r, k2) -> row n0, column k2 + 8 k1; then lane = k2 + 8 k1, register n0
             dft8(v);  // v[r] = Z[lane + 64 r]
             // ---- untangle the packed transform, |.|^2 (src/io/in.cc:388-394): bin k = lane + 64 r with Z[512 - k] from lane
             //      (64 - lane) % 64, register 7 - r (lane 0: register (8 - r) % 8, Z[512] = Z[0])
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void wave1k_kernel(const BigParams p, void *lp
                     cr = v[(8 - r) & 7].x;
                     ci = v[(8 - r) & 7].y;
                 }
-                const float2 a = v[r], w = twu[r];
+                const float2 a = v[r], w = ltw[lane + 64 * r];
                 const float sr = a.x + cr, si = a.y - ci, dr = a.x - cr, di = a.y + ci;
                 const float tr = w.x * di + w.y * dr, ti = w.y * di - w.x * dr;
                 const float ur = sr + tr, ui = si + ti;
@@ -292,8 +292,6 @@ __global__ __launch_bounds__(256) void wave1k_kernel(const BigParams p, void *lp
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // P, Y and the planes are rewritten by the next frame
-#pragma unroll
-            for (int j = 0; j < 8; j++) q[j] = qn[j];
         }
     }
 }
