@@ -233,6 +233,12 @@ def test_fft_sizes_above_512(Engine):
     _check(Engine, C3 + ["-w", "64", "-s", "16"], u16[:2])                               # PLP on exactly 1024 samples
     _check(Engine, C3 + ["-w", "50", "-s", "10", "-fb_inld", "off", "-fea_kind", "lpa", "-fea_ncepcoefs", "12"], u16[:2])
     _check(Engine, C2 + ["-w", "40", "-s", "10", "-fea_kind", "logspec", "-fea_E", "on", "-remove_dc", "off"], u16[:2])
+    # the edges of the 1024-point range, an odd window with an odd shift, 64 bands (one lane per bank segment), magnitude spectra
+    _check(Engine, C2 + ["-w", "32.0625", "-s", "10"], u16[:2])                            # 513 samples
+    _check(Engine, C2 + ["-w", "40.0625", "-s", "10.0625", "-fea_E", "on", "-fea_rawenergy", "on"], u16[:2])   # 641 / 161 samples
+    _check(Engine, C2 + ["-w", "64", "-s", "20", "-fb_definition", "64filters", "-fea_ncepcoefs", "20"], u16[:2])
+    _check(Engine, C2 + ["-w", "50", "-s", "12.5", "-fb_power", "off", "-fea_kind", "spec"], u16[:2], tol=1e-3)
+    _check(Engine, C3 + ["-w", "40", "-s", "10", "-fea_lporder", "16", "-fea_ncepcoefs", "18", "-fea_E", "on"], u16[:2])
     m44 = "-fs 44100 -format_in raw -format_out htk -preset mfcc -preem 0.97".split()
     u44 = [synth_utt(120 + i, 30000 + 5111 * i) for i in range(2)]
     _check(Engine, m44, u44)                                                            # 1102 samples -> 2048 points
