@@ -50,14 +50,6 @@ __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     v[7] = make_float2(b[6].x - b[7].x, b[6].y - b[7].y);
 }
 
-__device__ __forceinline__ float wave_sum_f(float x) {
-    x += dpp_mov<0x128>(x);
-    x += dpp_mov<0x124>(x);
-    x += dpp_mov<0x122>(x);
-    x += dpp_mov<0x121>(x);
-    return (lane_read(x, 0) + lane_read(x, 16)) + (lane_read(x, 32) + lane_read(x, 48));
-}
-
 constexpr int W1K_TS = 72;                       // dwords between the rows of the transpose plane
 constexpr int W1K_PLANE = 8 * W1K_TS;            // the plane: re and im of a transpose go through it one after the other; the power
                                                  // spectrum P[513 (+3)] takes its place once the transform is done
@@ -146,7 +138,7 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
                 }
             }
             if (p.remove_dc) {  // src/io/in.cc:375-382: the mean over `window` samples leaves the samples inside the window
-                const float m = wave_sum_f(part) / (float)p.window;
+                const float m = (float)(wave_sum_fast((double)part) / (double)p.window);  // a lane's 16 values in float, the wave's sum in double (as bigfft_kernel)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int i0 = 2 * lane + 128 * j;
