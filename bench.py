@@ -197,7 +197,7 @@ def other_configs(torch, dev, n_utt, steps, pcm16, host16, idx16):
             else:
                 idx = np.arange(n_utt)
                 plan = eng.plan(synth.lengths(set_id, idx))
-                host = synth.fill_arena(set_id, idx, plan.sample_off, plan.total_samples)
+                host = synth.fill_arena(set_id, idx, plan.sample_off, plan.total_samples, threads=max(1, min(32, _usable_cores()[2])))
                 pcm = torch.from_numpy(host).to(dev)
             d = eng.dims
             rows = torch.empty((plan.total_frames, d.row_floats), dtype=torch.float32, device=dev)
@@ -294,7 +294,10 @@ def main():
     all_frames = (all_len - (eng.dims.window - eng.dims.wshift)) // eng.dims.wshift
     mine = shard.lpt_shard(all_frames, world)[rank]
     plan = eng.plan(all_len[mine])
-    host = synth.fill_arena(synth.SET_SPEECH, mine, plan.sample_off, plan.total_samples)
+    # generator threads: this rank's share of the usable cores (eight ranks of a node each starting one thread per hardware
+    # thread would be thousands of tasks at once)
+    gen_threads = max(1, min(32, _usable_cores()[2] // max(world, 1)))
+    host = synth.fill_arena(synth.SET_SPEECH, mine, plan.sample_off, plan.total_samples, threads=gen_threads)
     pcm = torch.from_numpy(host).to(dev)
     rows = torch.empty((plan.total_frames, eng.dims.row_floats), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)

@@ -101,7 +101,7 @@ int64_t ctu_synth_fill(int32_t set, int64_t index, int32_t mini, int16_t *out, i
 int64_t ctu_synth_fill_arena(int32_t set, const int64_t *indices, int32_t mini, int32_t n_utt, const int64_t *sample_off,
                              int16_t *out, int32_t n_threads) {
     if (!indices || !sample_off || !out || n_utt < 0) return -1;
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : std::min(64, (int)std::thread::hardware_concurrency());  // 0: one per hardware thread, at most 64
     nt = std::max(1, std::min(nt, std::max(1, (int)n_utt)));
     std::atomic<int> next(0);
     std::atomic<int64_t> total(0);
