@@ -72,6 +72,19 @@ def test_c2_preset_mfcc(Engine):
     _check(Engine, C2, utts)
 
 
+def test_kernel_names_key_the_profiles(Engine):
+    # bench.py attaches the committed counter figures (profiles/traffic.json) only when they were taken on the kernel the engine runs
+    import json
+    import os
+    from tests.util import C4
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert Engine(C2).kernel_name() == json.load(open(os.path.join(root, "profiles", "traffic.json")))["kernel"]
+    assert Engine(C3).kernel_name() == "frontend_kernel<13, LP, MODE 0, inld>"
+    assert Engine(C4).kernel_name() == "frontend_kernel<13, DCTC, MODE 1, exten, MD, VF>"
+    assert Engine(C2 + ["-w", "40"]).kernel_name() == "wave1k_kernel"
+    assert Engine(C2 + ["-w", "80"]).kernel_name() == "bigfft_kernel<8>"
+
+
 def test_ragged_batch_and_tile_edges(Engine):
     # lengths chosen around the 64-frame tile: 1, 63, 64, 65, 128, 129 frames and an empty (0-frame) utterance
     frames = [1, 63, 64, 65, 128, 129, 0, 200]
