@@ -99,12 +99,12 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
     // after step 2, lane (n0 = d0, k2 = d1), register k1 = r: W512^(n0 (k2 + 8 k1)) = W1024^(2 n0 k2 + 16 n0 r)
     const int tw1_step = 16 * d1, tw2_base = 2 * d0 * d1, tw2_step = 16 * d0;
     const int mirror = ((64 - lane) & 63) << 2;
-    // output slots of the DCT rows this lane's 16-lane group takes in round i (row 4 i + lane / 16): read once, not per frame
-    int slot_of_round[8];
+    // output slots of the DCT rows 4 (lane / 16) + r this lane stores (-1: not written): read once, not per frame
+    int slot_of_row[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int r = 4 * i + (lane >> 4);
-        slot_of_round[i] = (p.feat == FEAT_DCTC && r < p.ncoef_out) ? p.row_slot[r] : -1;
+    for (int r = 0; r < 4; r++) {
+        const int row_ = 4 * (lane >> 4) + r;
+        slot_of_row[r] = (p.feat == FEAT_DCTC && row_ < p.ncoef_out) ? p.row_slot[row_] : -1;
     }
 
     const int gw = blockIdx.x * W1K_WAVES + wave, nw = gridDim.x * W1K_WAVES;
@@ -247,18 +247,34 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
                 const int out_w = p.band_to_scratch ? p.B : p.D;
                 if (lane < p.B) dst_[row * out_w + lane] = p.band_log ? Ylog[lane] : Y[lane];
             } else if (p.feat == FEAT_DCTC) {
-                // 16 lanes per coefficient, four coefficients per round: lane j sums bands j, j + 16, ..., then a row all-reduce
+                if (p.ncoef_out <= 16 && p.B <= 64) {
+                    // the DCT as a chain of v_mfma_f32_16x16x4_f32 (exact fp32 FMAs): A[m][kk] = row m of the folded table at band
+                    // 4 s + kk (lane = m + 16 kk), B[kk][n] = that band's logarithm in every column n: all 16 columns of D carry the
+                    // frame's coefficients, lane 16 q stores rows 4 q .. 4 q + 3
+                    const int m = lane & 15, kk = lane >> 4;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int s4 = 0; s4 < p.B; s4 += 4) {
+                        const int b = s4 + kk;
+                        const float av = (m < p.ncoef_out && b < p.B) ? lcoef[m * p.B + b] : 0.f;
+                        const float bv = b < p.B ? Ylog[b] : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    }
+                    if (m == 0) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (4 * i < p.ncoef_out) {
-                        const int r = 4 * i + (lane >> 4), j = lane & 15;
+                        for (int r = 0; r < 4; r++)
+                            if (slot_of_row[r] >= 0) p.rows[row * p.D + 4 * kk + r] = acc[r];
+                    }
+                } else {
+                    // more than 16 coefficients: 16 lanes per coefficient, four coefficients per round
+                    for (int r0_ = 0; r0_ < p.ncoef_out; r0_ += 4) {
+                        const int r = r0_ + (lane >> 4), j = lane & 15;
                         float acc = 0.f;
                         if (r < p.ncoef_out) {
                             const float *c = lcoef + r * p.B;
                             for (int b = j; b < p.B; b += 16) acc += c[b] * Ylog[b];
                         }
                         acc = row16_allreduce_add(acc);
-                        if (j == 0 && slot_of_round[i] >= 0) p.rows[row * p.D + r] = acc;
+                        if (j == 0 && r < p.ncoef_out && p.row_slot[r] >= 0) p.rows[row * p.D + r] = acc;
                     }
                 }
             } else {
