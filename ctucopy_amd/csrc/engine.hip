@@ -3,7 +3,10 @@
 //   kernel_common.h    constants, the kernel parameter block, DPP / LDS helpers, tile records
 //   frontend_kernel.h  PCM -> pre-emphasis * Hamming -> 512/256-pt real FFT in registers -> |.|^2 (P tile in LDS)
 //                      -> exten NR -> banded filter bank -> ^0.33 / log -> DCT-II + lifter | cosine iDFT + Levinson
-//   vad_kernels.h      Burg-cepstral criterion (packed inverse FFT + lattice, fp64), decision replay per utterance
+//   vad_kernels.h      Burg-cepstral criterion (packed inverse FFT + lattice), the detector's recurrences per utterance (one wave, or one
+//                      lane for the fused path)
+//   lp_tail_kernel.h   Levinson-Durbin and a -> c, one frame per lane
+//   wave1k_kernel.h    1024-point frames, one wave per frame
 //   trap_kernel.h      TRAP-DCT as fp32 MFMA Toeplitz contraction
 //   post_kernels.h     delta chain / stacking, CMS, per-speaker CMVN over resident rows
 //   signal_kernels.h   speech-enhancement output: inverse transform, overlap-add

@@ -56,10 +56,11 @@ namespace {
 // workgroup share each tile (wave w takes frame slots 8w..8w+7).  Per-wave chains (p.per_wave; exten): every wave
 // walks its own list of tiles, eight frames at a time, and keeps the state that runs along an utterance in its
 // registers.  Either way a wave only touches its own eight P rows: no workgroup barrier after the table load.
-// VF:     Burg-cepstral VAD criterion fused in (vad_fused.h; 256-point mode): the step's eight time-domain frames are
-//         rebuilt from the spectra after NR with the original phases and their cepstra written for the decision replay.
-// SS:     spectral subtraction with the Burg cepstral detector (hwss / fwss / 2fwss, src/nr/nr.cc:181-442; 256-point
-//         mode): the detector sees the frames rebuilt from the (expanded) spectra, so a step runs phase 1 twice - once to
+// VF:     Burg-cepstral VAD criterion fused in (vad_fused.h; 25 ms frames in the 256- and the 512-point mode): the step's eight
+//         time-domain frames are rebuilt from the spectra after NR with the original phases and their cepstra stored for
+//         vad_lanes_kernel (the detector's recurrences, one utterance per lane).
+// SS:     spectral subtraction with the Burg cepstral detector (hwss / fwss / 2fwss, src/nr/nr.cc:181-442; both modes,
+//         25 ms frames): the detector sees the frames rebuilt from the (expanded) spectra, so a step runs phase 1 twice - once to
 //         feed the detector, whose transposes and frames use up the P rows, once more for the subtraction itself.
 // SY:     speech-enhancement output (row N3, sigOUT src/io/out.cc:405-434): the step's spectra after NR go back to the time
 //         domain in registers (the inverse of vad_fused.h with the synthesis conventions) and the frames are written for
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     const int sl = MODE == 1 ? 2 * fg + x : 4 * x + fg;
                     if (sl < nv && l16 < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + l16] = mine_ab[x];
                 }
-                STAMP(13);  // VF: decision replay of the step's frames
+                STAMP(13);  // VF: cepstra stored
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
