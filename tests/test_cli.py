@@ -353,3 +353,34 @@ def test_bench_two_ranks_smoke():
     assert j["n_gpus"] == 2 and len(j["config"]["frames_per_rank"]) == 2 and j["scaling"] == "weak"
     assert j["validated"]["rows_finite"] and j["validated"]["worst_rel_err"] <= 1e-4
     assert abs(j["config"]["frames_per_rank"][0] - j["config"]["frames_per_rank"][1]) <= 1500
+
+
+@pytest.mark.gpu
+def test_spectral_subtraction_list_is_one_chain(tmp_path):
+    """-nr_mode fwss -vad burg through the CLI at 16 kHz: the files of the list are one chain through the noise seed
+    (src/nr/nr.cc:212-221), a file without a frame scales the stale vector (nr.cc:219), --gpus N falls back to one GPU."""
+    from tests.util import C2, synth_utt
+    cfg = C2 + ["-vad", "burg", "-nr_mode", "fwss"]
+    lens = [30000, 12000, 240, 20000, 9000]            # 240 samples: the pre-load and no hop
+    lines, utts = [], []
+    for i, n in enumerate(lens):
+        f = tmp_path / f"u{i}.raw"
+        u = synth_utt(500 + i, n)
+        u.astype("<i2").tofile(f)
+        utts.append(u)
+        lines.append(f"{f} {tmp_path / f'u{i}.htk'}")
+    (tmp_path / "list").write_text("\n".join(lines) + "\n")
+    r = run(cfg + ["-S", str(tmp_path / "list"), "--gpus", "2", "-v"])
+    assert r.returncode == 0, r.stderr
+    assert "chains the files of the list" in r.stderr
+    orc = Oracle(cfg)
+    for i, u in enumerate(utts):
+        ref = orc.process(u)
+        raw = (tmp_path / f"u{i}.htk").read_bytes()
+        n, period, nbytes, kind = struct.unpack("<IIHH", raw[:12])
+        assert (n, nbytes) == (ref.shape[0], 52)
+        got = np.frombuffer(raw[12:], dtype="<f4").reshape(-1, 13)
+        if ref.size:
+            e = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+            rn = np.abs(got - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1.0)
+            assert e.max() <= 1e-3 and rn.max() <= 1e-4, (i, float(e.max()), float(rn.max()))   # the conditioning class of an NR configuration
