@@ -157,6 +157,7 @@ struct ctu_plan {
     }
     DevBuf<int> tile_utt;            // utterance of every tile (SS)
     DevBuf<float> ss_seed, ss_last;  // SS: noise seeds per utterance [n_utt][K] and the vectors the utterances leave behind
+    DevBuf<unsigned char> ss_dirty;  // SS: utterances a pass of the seed iteration recomputes
     DevBuf<float2> xri;         // VAD scratch
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
@@ -1164,6 +1165,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             pl->tile_utt.upload(tu);
             pl->ss_seed.alloc((size_t)std::max(n_utt, 1) * d.K);
             pl->ss_last.alloc((size_t)std::max(n_utt, 1) * d.K);
+            pl->ss_dirty.alloc((size_t)std::max(n_utt, 1));
         }
         if (e->do_vad) {
             pl->d_row_off.upload(pl->row_off);
@@ -1426,13 +1428,23 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 return std::make_pair(prev, skipped);
             };
             propagate(seed);  // `last` is still zero: only the seeds ahead of the first file with a frame are final
+            // An utterance's rows and last vector depend on its samples and its seed only: a pass recomputes just the utterances
+            // whose seed changed since the pass before (all of them in the first one).
+            std::vector<unsigned char> dirty(std::max(pl->n_utt, 1), 1);
+            kp.ss_dirty = pl->ss_dirty.p;
             for (int iter = 0;; iter++) {
                 HIP_TRY(hipMemcpyAsync(pl->ss_seed.p, seed.data(), nk * sizeof(float), hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemcpyAsync(pl->ss_dirty.p, dirty.data(), dirty.size(), hipMemcpyHostToDevice, s));
                 launch();
                 HIP_TRY(hipMemcpyAsync(last.data(), pl->ss_last.p, nk * sizeof(float), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 propagate(next);
-                if (std::memcmp(next.data(), seed.data(), nk * sizeof(float)) == 0) break;
+                bool any = false;
+                for (int i = 0; i < pl->n_utt; i++) {
+                    dirty[i] = std::memcmp(&next[(size_t)i * d.K], &seed[(size_t)i * d.K], d.K * sizeof(float)) != 0;
+                    any = any || dirty[i];
+                }
+                if (!any) break;
                 if (iter > pl->n_utt) throw std::runtime_error("internal: noise seeds of the *ss chain did not settle");
                 seed = next;
             }

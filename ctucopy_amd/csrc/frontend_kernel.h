@@ -173,7 +173,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         const int next = rec.next;
         TileRec nrec = rec;
         if (next >= 0) nrec = load_rec(p.tiles, next);
-        const int nsub = per_wave ? (nvalid + 7) >> 3 : 1;
+        // SS, second and later passes of the seed iteration (engine.hip): an utterance whose seed did not change keeps its rows
+        const bool skip_tile = SS && p.ss_dirty && !reinterpret_cast<const unsigned char *>(p.ss_dirty)[as_const(p.tile_utt)[tile]];
+        const int nsub = skip_tile ? 0 : (per_wave ? (nvalid + 7) >> 3 : 1);
         for (int sub = 0; sub < nsub; sub++) {
         // this step's frame slots are [slot0, slot0 + 8) of the tile; their spectra live in the wave's P rows 0..7
         const int slot0 = per_wave ? sub * 8 : wave * 8;
@@ -1081,6 +1083,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         }  // steps of 8 frames
         if (next < 0) break;
         rec = nrec;
+        tile = next;  // SS looks its utterance up by tile (seed in, last vector out)
     }
 #if CTU_STAMP
     if (lane == 0 && p.stamps)

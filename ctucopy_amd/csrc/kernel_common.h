@@ -89,6 +89,7 @@ struct KParams {
     const float *ss_seed;
     float *ss_last;
     const int *tile_utt;
+    const unsigned char *ss_dirty;  // [n_utt] or null: utterances to (re)compute in this pass of the seed iteration
     float *ybuf;      // SY instantiations: time-domain frames [total_frames][window] ahead of the overlap-add
     float syn_scale;  // SY: 1 / wfft (sigOUT's amplitude factor, src/io/out.cc:416-422)
     float *vad_cf;    // VF instantiations: Burg cepstra of every frame [total_frames][VFC_STRIDE] for vad_lanes_kernel

@@ -799,6 +799,28 @@ def test_spectral_subtraction_frameless_file_scales_the_seed(Engine):
     assert not np.allclose(twice[-1][:2], got[6][:2], rtol=1e-3, atol=0)
 
 
+def test_spectral_subtraction_more_utterances_than_chains(Engine):
+    # a wave walks a chain of whole utterances and looks each one's seed up by tile: with more utterances than chains (4096 waves at
+    # most) a chain holds several.  6000 short files at 8 kHz, every one against the oracle's sequential walk of the list.
+    cfg = SS8 + ["-nr_mode", "fwss"]
+    rng = np.random.default_rng(5)
+    base = synth_utt(77, 8000 * 60, fs=8000)
+    utts = []
+    for i in range(6000):
+        n = int(rng.integers(120 + 80 * 3, 120 + 80 * 40))
+        o = int(rng.integers(0, base.size - n))
+        utts.append(base[o:o + n])
+    got = Engine(cfg).extract(utts)
+    orc = Oracle(cfg)
+    worst = rown = 0.0
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        worst = max(worst, rel_err(g, ref))
+        rown = max(rown, float((np.abs(g - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1.0)).max()))
+    assert worst <= 1e-3 and rown <= 1e-4, (worst, rown)
+
+
 def test_spectral_subtraction_refusals(Engine):
     from ctucopy_amd import CtuError
     for cfg in (C2 + ["-nr_mode", "fwss", "-vad", "burg", "-w", "20"],        # a 320-sample window: not one of the fused frame shapes
