@@ -355,6 +355,8 @@ def test_c4_burg_cepstral_vad(Engine):
     ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "absolute", "-vad_absolute_thr", "150"],
     ["-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "adapt"],
     ["-vad", "burg", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_thr_mode", "adapt"],
+    ["-nr_mode", "exten", "-nr_a", "2", "-vad", "burg", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_thr_mode", "adapt"],   # configs[3] at 16 kHz
+    ["-vad", "burg", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_thr_mode", "dyn", "-fea_Z_exp", "500"],
 ])
 def test_vad_modes_16k(Engine, extra):
     # decisions are states, not a percentage: a flipped byte changes the thresholds' recurrences for the rest of the file, so
