@@ -162,7 +162,7 @@ struct ctu_plan {
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
     DevBuf<float> vad_cf;      // fused Burg-cepstral VAD: cepstra of every frame [total_frames][VFC_STRIDE] ahead of vad_lanes_kernel
-    DevBuf<int> vf_order;      // utterances with at least one frame, longest first (a wave of vad_lanes_kernel takes 64 in a row)
+    DevBuf<int> vf_order;      // utterances with at least one frame, longest first (a wave of vad_lanes_kernel takes 16 in a row)
     int n_live = 0;
     DevBuf<int64_t> d_row_off;
     DevBuf<double> dc1m;       // -remove_dc1: frame means, then
@@ -1579,8 +1579,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             HIP_TRY(hipGetLastError());
         }
         if (e->do_vad && e->vf && pl->n_live > 0) {
-            // the fused path left the Burg cepstra of every frame behind: the detector's recurrences, one utterance per lane
-            hipLaunchKernelGGL((vad_lanes_kernel<VF_NC>), dim3((pl->n_live + 63) / 64), dim3(64), 0, s, pl->vad_cf.p, pl->vf_order.p, pl->n_live,
+            // the fused path left the Burg cepstra of every frame behind: the detector's recurrences, sixteen utterances per wave
+            hipLaunchKernelGGL((vad_lanes_kernel<VF_NC>), dim3((pl->n_live + 15) / 16), dim3(64), 0, s, pl->vad_cf.p, pl->vf_order.p, pl->n_live,
                                pl->d_row_off.p, d_vad, e->vp);
             HIP_TRY(hipGetLastError());
         }

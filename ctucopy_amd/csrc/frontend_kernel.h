@@ -58,7 +58,7 @@ namespace {
 // registers.  Either way a wave only touches its own eight P rows: no workgroup barrier after the table load.
 // VF:     Burg-cepstral VAD criterion fused in (vad_fused.h; 25 ms frames in the 256- and the 512-point mode): the step's eight
 //         time-domain frames are rebuilt from the spectra after NR with the original phases and their cepstra stored for
-//         vad_lanes_kernel (the detector's recurrences, one utterance per lane).
+//         vad_lanes_kernel (the detector's recurrences, four lanes per utterance).
 // SS:     spectral subtraction with the Burg cepstral detector (hwss / fwss / 2fwss, src/nr/nr.cc:181-442; both modes,
 //         25 ms frames): the detector sees the frames rebuilt from the (expanded) spectra, so a step runs phase 1 twice - once to
 //         feed the detector, whose transposes and frames use up the P rows, once more for the subtraction itself.

@@ -300,30 +300,31 @@ __device__ __forceinline__ void vad_flush(VadRun &r, const VadParams &vp, int T,
     }
 }
 
-// The same recurrences with one UTTERANCE PER LANE, for the fused Burg-cepstral path (vad_fused.h): the front end leaves
-// the cepstra of every frame in a scratch row (VFC_STRIDE floats) and a wave of this kernel walks 64 utterances at once.
-// Inside the front end the replay ran eight strictly sequential frames per wave step with all 64 lanes doing one
-// utterance's scalar work - a quarter of that kernel (profiles/r02_c4_vf_stamps.txt); here every lane carries its own
-// utterance, and the launch lasts as long as its longest one.  The distance is summed over the coefficients in order, as
-// the reference does (src/vad/vad.cc:239-247); everything else is vad_frame / vad_flush statement for statement.
+// The same recurrences for the fused Burg-cepstral path (vad_fused.h) with the utterances spread over the LANES: the front end
+// leaves the cepstra of every frame in a scratch row (VFC_STRIDE floats) and a wave of this kernel walks 16 utterances at once, four
+// lanes each - a lane keeps four coefficients of the background cepstrum and adds four terms to the distance (two quad_perm adds
+// bring the four partial sums together, the same value in the four lanes); the scalar state is replicated in the quad and evolves
+// identically.  Inside the front end the replay ran eight strictly sequential frames per wave step with all 64 lanes doing one
+// utterance's scalar work - a quarter of that kernel (profiles/r02_c4_vf_stamps.txt).  The launch lasts as long as its longest
+// utterance; everything but the distance's summation order is vad_frame / vad_flush statement for statement.
 constexpr int VFC_STRIDE = 16;  // floats per frame in the cepstra scratch: the fused path's 14 coefficients, 64-byte rows
 
-template <int NCL>
+template <int NCL>  // cepstral coefficients (<= 16)
 __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__ cf, const int *__restrict__ order, int n_live,
                                                         const int64_t *__restrict__ row_off, uint8_t *__restrict__ vad_out, VadParams vp) {
-    const int gidx = blockIdx.x * 64 + threadIdx.x;
+    static_assert(NCL <= 16, "four lanes x four coefficients");
+    const int lane = threadIdx.x, pq = lane & 3;
+    const int gidx = blockIdx.x * 16 + (lane >> 2);
     const bool live = gidx < n_live;
     const int u = live ? order[gidx] : 0;
     const int64_t r0 = live ? row_off[u] : 0;
     const int T = live ? (int)(row_off[u + 1] - r0) : 0;
     int Tmax = T;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, off, 64));
+    for (int off = 32; off >= 4; off >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, off, 64));
     const int order_f = vp.filter_order, h = (order_f - 1) / 2;
     double crimin = 0, crimax = 0, crimean = 0, crimean2 = 0, crivar = 0, dmin = 0, dmax = 0;
-    double c0[NCL];
-#pragma unroll
-    for (int i = 0; i < NCL; i++) c0[i] = 0.0;
+    double c0[4] = {0.0, 0.0, 0.0, 0.0};   // coefficients 4 pq .. 4 pq + 3 of the background cepstrum
     int adapt_vad = 0, hidx = 0, nout = 0, nsum = 0;
     unsigned long long hist = 0;
     uint8_t *out = vad_out + r0;
@@ -333,13 +334,10 @@ __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__
         nsum += v - old;
         hidx = (hidx + 1 == order_f) ? 0 : hidx + 1;
     };
-    constexpr int AHEAD = 4;  // frames whose cepstra are in flight while the current ones are worked on (one wave per SIMD: no other cover)
-    float4 q[AHEAD][NCL / 4 + (NCL % 4 ? 1 : 0)];
-    constexpr int NQ = NCL / 4 + (NCL % 4 ? 1 : 0);
+    constexpr int AHEAD = 4;  // frames whose cepstra are in flight while the current ones are worked on (few waves per SIMD: no other cover)
+    float4 q[AHEAD];
     auto fetch = [&](int slot, int t) {
-        const float4 *src = reinterpret_cast<const float4 *>(cf + (r0 + (t < T ? t : 0)) * VFC_STRIDE);
-#pragma unroll
-        for (int j = 0; j < NQ; j++) q[slot][j] = (t < T) ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        q[slot] = (t < T) ? reinterpret_cast<const float4 *>(cf + (r0 + t) * VFC_STRIDE)[pq] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 #pragma unroll
     for (int a = 0; a < AHEAD; a++) fetch(a, a);
@@ -347,32 +345,31 @@ __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__
 #pragma unroll
         for (int a = 0; a < AHEAD; a++) {
             const int t = tb + a;
-            double ci[NCL];
-#pragma unroll
-            for (int i = 0; i < NCL; i++) {
-                const float4 v = q[a][i >> 2];
-                ci[i] = (double)((i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w);
-            }
+            const double ci[4] = {(double)q[a].x, (double)q[a].y, (double)q[a].z, (double)q[a].w};
             fetch(a, t + AHEAD);
-            if (t < T) {
-                double cri;
-                if (t == 0) {
+            // the quad's lanes run the same scalar code on the same values: a lane beyond its utterance's end just idles in step
+            double cri;
+            if (t == 0) {
 #pragma unroll
-                    for (int i = 0; i < NCL; i++) c0[i] = ci[i];
-                    cri = 0.0;
-                } else {
-                    if (t == 1) {
+                for (int i = 0; i < 4; i++) c0[i] = ci[i];
+                cri = 0.0;
+            } else {
+                if (t == 1) {
 #pragma unroll
-                        for (int i = 0; i < NCL; i++) c0[i] = (c0[i] + ci[i]) / 2.0;
-                    }
-                    double sum = 0.0;  // c0 itself is not part of the distance
-#pragma unroll
-                    for (int i = 1; i < NCL; i++) {
-                        const double dl = ci[i] - c0[i];
-                        sum += dl * dl;
-                    }
-                    cri = 4.3429 * sqrt(2 * sum);
+                    for (int i = 0; i < 4; i++) c0[i] = (c0[i] + ci[i]) / 2.0;
                 }
+                double sum = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = 4 * pq + i;
+                    const double dl = (k >= 1 && k < NCL) ? ci[i] - c0[i] : 0.0;  // c0 itself is not part of the distance
+                    sum += dl * dl;
+                }
+                sum += dpp_mov<0xB1>(sum);  // quad_perm [1,0,3,2]
+                sum += dpp_mov<0x4E>(sum);  // quad_perm [2,3,0,1]
+                cri = 4.3429 * sqrt(2 * sum);
+            }
+            if (t < T) {
                 int vad0;
                 if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
                 else if (vp.thr == 1) {
@@ -416,11 +413,11 @@ __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__
                 }
                 if (!(vad0 && t > vp.cep_init)) {  // background update (src/vad/vad.cc:288-294)
 #pragma unroll
-                    for (int i = 0; i < NCL; i++) c0[i] = vp.cep_p * c0[i] + (1.0 - vp.cep_p) * ci[i];
+                    for (int i = 0; i < 4; i++) c0[i] = vp.cep_p * c0[i] + (1.0 - vp.cep_p) * ci[i];
                 }
                 push(vad0);
                 if (t >= h) {
-                    out[nout] = (2 * nsum >= order_f) ? '1' : '0';
+                    if (pq == 0) out[nout] = (2 * nsum >= order_f) ? '1' : '0';
                     nout++;
                 }
             }
@@ -428,7 +425,7 @@ __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__
     }
     for (int k = 0; k < h && nout < T; k++) {  // end of the utterance: zeros until every frame has its byte (src/vad/vad.h:156-175)
         push(0);
-        out[nout] = (2 * nsum >= order_f) ? '1' : '0';
+        if (pq == 0) out[nout] = (2 * nsum >= order_f) ? '1' : '0';
         nout++;
     }
 }
