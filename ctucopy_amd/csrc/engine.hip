@@ -334,7 +334,7 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
     // ---- phase-2 tables.  Bands are dealt to (slot, group) cells: sorted by width, eight per slot, so that the
     // eight lanes of a frame walk bands of similar width in lock step.  A band is cut into 4-bin chunks whose
     // bin range stays inside [0,K); weights outside the band's own [first,last] are zero.
-    const int B = d.B, K = d.K;
+    const int B = d.B;
     std::vector<int> order(B);
     for (int b = 0; b < B; b++) order[b] = b;
     auto width = [&](int b) { return d.fb_last[b] - d.fb_first[b] + 1; };

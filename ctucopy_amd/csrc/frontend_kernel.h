@@ -102,8 +102,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
     const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
     const int fg = lane >> 4;    // frame slot within the wave pass
     const int partner = ((lane & 48) | ((16 - l16) & 15)) << 2;  // byte address for ds_bpermute
-    ci32 *slot_chunk = as_const(p.itab), *row_slot = slot_chunk + p.NS + 1;
-    cf32 *ftab = as_const(p.ftab);
+    ci32 *slot_chunk = as_const(p.itab);  // (row slots and the lifter, behind it in the tables, are lp_tail_kernel's)
     for (int i = tid; i < p.tab_floats; i += WG) ltab[i] = p.ftab[i];
     for (int i = tid; i < 16 * LANEC; i += WG) ltw[(i / LANEC) * LTW_STRIDE + (i % LANEC)] = p.lanec[i];
     // Phase 2 reads whole 4-bin chunks, so bins a frame never writes (row padding 257..259; everything above bin
