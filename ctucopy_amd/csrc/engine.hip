@@ -1049,6 +1049,18 @@ int64_t ctu_num_frames(const ctu_engine *e, int64_t n) {
     return (n - pre) / e->design->wshift;
 }
 
+int64_t ctu_arena_layout(const int64_t *utt_nsamples, int32_t n_utt, int64_t *sample_off) {
+    if (n_utt < 0 || (n_utt && !utt_nsamples)) return CTU_ERR_INPUT;
+    int64_t so = PCM_HEAD;
+    for (int i = 0; i < n_utt; i++) {
+        if (utt_nsamples[i] < 0) return CTU_ERR_INPUT;
+        if (sample_off) sample_off[i] = so;
+        so += (utt_nsamples[i] + PCM_ALIGN - 1) / PCM_ALIGN * PCM_ALIGN;
+    }
+    if (sample_off) sample_off[n_utt] = so;
+    return so + PCM_TAIL;  // loads run to the end of the last 32-sample row of a frame
+}
+
 int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, ctu_plan **out) {
     if (!e || !out || n_utt < 0 || (n_utt && !utt_nsamples)) return CTU_ERR_INPUT;
     *out = nullptr;
@@ -1060,7 +1072,12 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
     pl->row_off.resize(n_utt + 1);
     pl->frames.resize(n_utt);
     const ctu::Design &d = *e->design;
-    int64_t so = PCM_HEAD, ro = 0;
+    int64_t ro = 0;
+    pl->total_samples = ctu_arena_layout(utt_nsamples, n_utt, pl->sample_off.data());
+    if (pl->total_samples < 0) {
+        set_error(e, "ENGINE: negative utterance length");
+        return CTU_ERR_INPUT;
+    }
     std::vector<TileRec> tiles;
     std::vector<int> uts(n_utt + 1, 0);
     std::vector<int4> uinfo(n_utt);
@@ -1087,7 +1104,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             set_error(e, "ENGINE: trapdct on fewer than (traplen+1)/2 frames is undefined in the reference (src/fea/fea_trap.cc:64-70)");
             return CTU_ERR_INPUT;
         }
-        pl->sample_off[i] = so;
+        const int64_t so = pl->sample_off[i];
         pl->row_off[i] = ro;
         pl->frames[i] = T;
         uts[i] = (int)tiles.size();
@@ -1106,13 +1123,10 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             chunks.push_back(i);
             chunks.push_back((int)tc);
         }
-        so += (utt_nsamples[i] + PCM_ALIGN - 1) / PCM_ALIGN * PCM_ALIGN;
         ro += T;
     }
     uts[n_utt] = (int)tiles.size();
-    pl->sample_off[n_utt] = so;
     pl->row_off[n_utt] = ro;
-    pl->total_samples = so + PCM_TAIL;  // loads run to the end of the last 32-sample row of a frame
     pl->total_frames = ro;
     pl->n_tiles = (int)tiles.size();
     // Each workgroup walks a chain of tiles.  Stateless chains stride over the tile list; with a

@@ -31,7 +31,7 @@ class Dims(ctypes.Structure):
 # every symbol include/ctu_engine.h declares (checked by tests/test_abi.py)
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
-           "ctu_plan_row_offsets", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
+           "ctu_plan_row_offsets", "ctu_arena_layout", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
            "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
@@ -68,6 +68,8 @@ def load_library():
     L.ctu_plan_sample_offsets.argtypes = [vp]
     L.ctu_plan_row_offsets.restype = ctypes.POINTER(i64)
     L.ctu_plan_row_offsets.argtypes = [vp]
+    L.ctu_arena_layout.restype = i64
+    L.ctu_arena_layout.argtypes = [ctypes.POINTER(i64), ctypes.c_int32, ctypes.POINTER(i64)]
     L.ctu_plan_total_samples.restype = i64
     L.ctu_plan_total_samples.argtypes = [vp]
     L.ctu_plan_total_frames.restype = i64

@@ -6,23 +6,37 @@
 // :648-781, ICSI pfile src/io/pfile.cc:435-592), so that it is a drop-in for batch feature extraction.
 // The per-frame chain itself runs on the GPU(s) behind include/ctu_engine.h; this file only moves bytes.
 //
-// Host loop (the counterpart of BATCH::process, src/io/batch.cc:326-421): files are decoded into a packed PCM
-// arena in bounded batches, utterances of a batch are sharded over the GPUs by frame count (no collective:
-// every utterance is independent), results are written in list order.
+// Host loop (the counterpart of BATCH::process, src/io/batch.cc:326-421), three stages that overlap batch by batch:
+//   reader   - sizes the next files, shards them over the GPUs by length (LPT; no collective: every utterance is
+//              independent), lays each shard out with ctu_arena_layout and reads / decodes the files straight into
+//              page-locked arenas with a pool of I/O threads;
+//   engines  - one thread per GPU: ctu_plan_create + ctu_engine_run_host on its shard;
+//   writer   - HTK / raw / WAVE / VAD files by the same pool straight from the page-locked rows, ark / pfile and the
+//              verbose lines in list order.
+// Files before a failing one are written as far as their batch got through, then the reference's message and exit
+// status -1 (src/main.cpp:54-60).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "g711.h"
 #include "ctu_engine.h"
@@ -39,48 +53,72 @@ struct Item {
 };
 
 // ---------------------------------------------------------------- decoders
-std::vector<uint8_t> read_all(const std::string &path, const char *err) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) throw Fatal(err);
-    std::vector<uint8_t> buf;
-    uint8_t tmp[1 << 16];
-    size_t n;
-    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
-    std::fclose(f);
-    return buf;
-}
-
 uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-std::vector<int16_t> decode(const ctu::Opts &o, const std::string &path) {
-    std::vector<int16_t> pcm;
-    if (o.format_in == "raw") {
-        const std::vector<uint8_t> b = read_all(path, "IN: Cannot open data file!");
-        pcm.resize(b.size() / 2);
-        for (size_t i = 0; i < pcm.size(); i++)
-            pcm[i] = (int16_t)(o.swap_in ? (b[2 * i] << 8 | b[2 * i + 1]) : (b[2 * i + 1] << 8 | b[2 * i]));
-    } else if (o.format_in == "alaw" || o.format_in == "mulaw") {
-        const std::vector<uint8_t> b = read_all(path, "IN: Cannot open data file!");
-        pcm.resize(b.size());
-        const bool alaw = o.format_in == "alaw";
-        for (size_t i = 0; i < b.size(); i++) pcm[i] = g711_to_linear(b[i], alaw);
-    } else if (o.format_in == "wave") {  // canonical 44-byte header only, like src/io/in.cc:550-597
-        const std::vector<uint8_t> b = read_all(path, "IN: Cannot open file!");
-        if (b.size() < 44 || std::memcmp(b.data(), "RIFF", 4)) throw Fatal("IN: No RIFF header in file!");
-        if (std::memcmp(b.data() + 8, "WAVE", 4)) throw Fatal("IN: Not a WAVE file!");
-        if (rd16(&b[20]) != 1) throw Fatal("IN: Not a PCM WAVE file!");
-        if ((long)rd32(&b[24]) != o.fs) throw Fatal("IN: WAVE file reports different sampling rate than specified!");
-        if (rd16(&b[22]) != 1) throw Fatal("IN: Input WAVE file is not mono!");
-        if (rd16(&b[34]) != 16) throw Fatal("IN: Not 16 bits per sample!");
-        size_t n = rd32(&b[40]) / 2;
-        n = std::min(n, (b.size() - 44) / 2);
-        pcm.resize(n);
-        for (size_t i = 0; i < n; i++) pcm[i] = (int16_t)rd16(&b[44 + 2 * i]);
-    } else {
-        throw Fatal("IN: Unknown input file format!");
+struct FileCloser {
+    void operator()(FILE *f) const {
+        if (f) std::fclose(f);
     }
-    return pcm;
+};
+typedef std::unique_ptr<FILE, FileCloser> File;
+
+// canonical 44-byte WAVE header only, like src/io/in.cc:550-597; returns the number of samples the file holds
+size_t wave_samples(const ctu::Opts &o, FILE *f, size_t file_bytes) {
+    uint8_t b[44];
+    if (file_bytes < 44 || std::fread(b, 1, 44, f) != 44 || std::memcmp(b, "RIFF", 4)) throw Fatal("IN: No RIFF header in file!");
+    if (std::memcmp(b + 8, "WAVE", 4)) throw Fatal("IN: Not a WAVE file!");
+    if (rd16(&b[20]) != 1) throw Fatal("IN: Not a PCM WAVE file!");
+    if ((long)rd32(&b[24]) != o.fs) throw Fatal("IN: WAVE file reports different sampling rate than specified!");
+    if (rd16(&b[22]) != 1) throw Fatal("IN: Input WAVE file is not mono!");
+    if (rd16(&b[34]) != 16) throw Fatal("IN: Not 16 bits per sample!");
+    return std::min<size_t>(rd32(&b[40]) / 2, (file_bytes - 44) / 2);
+}
+
+// number of samples `path` will decode to, without reading its data
+int64_t probe_samples(const ctu::Opts &o, const std::string &path) {
+    const bool wave = o.format_in == "wave";
+    if (o.format_in != "raw" && o.format_in != "alaw" && o.format_in != "mulaw" && !wave) throw Fatal("IN: Unknown input file format!");
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) {
+        // not a plain file (or missing): let fopen decide, sizes by reading to the end
+        File f(std::fopen(path.c_str(), "rb"));
+        if (!f) throw Fatal(wave ? "IN: Cannot open file!" : "IN: Cannot open data file!");
+        size_t n = 0, got;
+        uint8_t tmp[1 << 16];
+        while ((got = std::fread(tmp, 1, sizeof tmp, f.get())) > 0) n += got;
+        if (wave) {
+            std::rewind(f.get());
+            return (int64_t)wave_samples(o, f.get(), n);
+        }
+        return (int64_t)(o.format_in == "raw" ? n / 2 : n);
+    }
+    const size_t bytes = (size_t)st.st_size;
+    if (wave) {
+        File f(std::fopen(path.c_str(), "rb"));
+        if (!f) throw Fatal("IN: Cannot open file!");
+        return (int64_t)wave_samples(o, f.get(), bytes);
+    }
+    return (int64_t)(o.format_in == "raw" ? bytes / 2 : bytes);
+}
+
+// reads `n` samples of `path` into dst (raw / a-law / mu-law / WAVE, src/io/in.cc:434-619, src/io/amulaw.h:20-53)
+void decode_into(const ctu::Opts &o, const std::string &path, int16_t *dst, size_t n) {
+    const bool wave = o.format_in == "wave";
+    File f(std::fopen(path.c_str(), "rb"));
+    if (!f) throw Fatal(wave ? "IN: Cannot open file!" : "IN: Cannot open data file!");
+    if (wave && std::fseek(f.get(), 44, SEEK_SET) != 0) throw Fatal("IN: No RIFF header in file!");
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(dst);
+    if (o.format_in == "alaw" || o.format_in == "mulaw") {
+        // the codes go to the upper half of the samples' own bytes and are expanded from the front (code i sits at byte n + i >= 2 i + 1)
+        if (std::fread(bytes + n, 1, n, f.get()) != n) throw Fatal("IN: Cannot read data file!");
+        const bool alaw = o.format_in == "alaw";
+        for (size_t i = 0; i < n; i++) dst[i] = g711_to_linear(bytes[n + i], alaw);
+        return;
+    }
+    if (std::fread(bytes, 2, n, f.get()) != n) throw Fatal("IN: Cannot read data file!");
+    if (o.swap_in && !wave)
+        for (size_t i = 0; i < n; i++) dst[i] = (int16_t)((uint16_t)dst[i] << 8 | (uint16_t)dst[i] >> 8);
 }
 
 // ---------------------------------------------------------------- writers
@@ -108,15 +146,27 @@ void write_file(const std::string &path, const std::vector<uint8_t> &bytes, cons
 
 // HTK: nSamples, sampPeriod (100 ns), sampSize (bytes), parmKind, then float32 rows (src/io/out.cc:115-213)
 void write_htk(const std::string &path, const float *rows, int64_t n, const ctu_dims &d) {
-    std::vector<uint8_t> b;
-    b.reserve(12 + (size_t)n * d.row_floats * 4);
+    std::vector<uint8_t> h;
     const bool big = d.swap_out;
-    put32(b, (uint32_t)n, big);
-    put32(b, d.htk_period, big);
-    put16(b, (uint16_t)(4 * d.row_floats), big);
-    put16(b, (uint16_t)d.htk_kind, big);
-    for (int64_t i = 0; i < n * d.row_floats; i++) putf(b, rows[i], big);
-    write_file(path, b, "OUT: Cannot create output file!");
+    put32(h, (uint32_t)n, big);
+    put32(h, d.htk_period, big);
+    put16(h, (uint16_t)(4 * d.row_floats), big);
+    put16(h, (uint16_t)d.htk_kind, big);
+    File f(std::fopen(path.c_str(), "wb"));
+    if (!f) throw Fatal("OUT: Cannot create output file!");
+    const size_t nf = (size_t)n * d.row_floats;
+    bool ok = std::fwrite(h.data(), 1, h.size(), f.get()) == h.size();
+    if (!big) ok = ok && (nf == 0 || std::fwrite(rows, 4, nf, f.get()) == nf);  // rows are little-endian float32 as they stand
+    else {
+        std::vector<uint32_t> sw(nf);
+        for (size_t i = 0; i < nf; i++) {
+            uint32_t x;
+            std::memcpy(&x, rows + i, 4);
+            sw[i] = __builtin_bswap32(x);
+        }
+        ok = ok && (nf == 0 || std::fwrite(sw.data(), 4, nf, f.get()) == nf);
+    }
+    if (!ok) throw Fatal("OUT: Error in stream writing!");
 }
 
 // KALDI binary matrix archive + index (src/io/out.cc:648-781)
@@ -215,76 +265,24 @@ struct Gpu {
     }
 };
 
-void run_shard(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> &utts, std::vector<std::vector<float>> &out,
-               std::vector<std::string> &vad_out, bool has_vad, int row_floats, std::string &err) {
-    std::vector<int64_t> ns;
-    for (auto *u : utts) ns.push_back((int64_t)u->size());
-    ctu_plan *plan = nullptr;
-    if (ctu_plan_create(eng, ns.data(), (int)ns.size(), &plan) != CTU_OK) {
-        err = ctu_last_error(eng);
-        return;
-    }
-    const int64_t *so = ctu_plan_sample_offsets(plan), *ro = ctu_plan_row_offsets(plan);
-    // page-locked staging for the arena and the rows: DMA at the link rate (include/ctu_engine.h, ctu_host_alloc)
-    const size_t ns_total = (size_t)ctu_plan_total_samples(plan), nr_total = (size_t)ctu_plan_total_frames(plan) * row_floats;
-    int16_t *arena = static_cast<int16_t *>(ctu_host_alloc(ns_total * sizeof(int16_t)));
-    float *rows = static_cast<float *>(ctu_host_alloc((nr_total ? nr_total : 1) * sizeof(float)));
-    if (!arena || !rows) {
-        err = "ENGINE: cannot allocate page-locked host memory";
-        ctu_host_free(arena);
-        ctu_host_free(rows);
-        ctu_plan_destroy(plan);
-        return;
-    }
-    std::memset(arena, 0, ns_total * sizeof(int16_t));
-    for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena + so[i]);
-    std::vector<uint8_t> vad(has_vad ? (size_t)ctu_plan_total_frames(plan) : 0);
-    std::vector<int64_t> kept(utts.size());
-    if (ctu_engine_run_host(eng, plan, arena, rows, has_vad ? vad.data() : nullptr, kept.data()) != CTU_OK)
-        err = ctu_last_error(eng);
-    else
-        for (size_t i = 0; i < utts.size(); i++) {
-            // rows_per_utt < frames only with -vad_apply_mode drop (rows compacted in place by the library)
-            out[i].assign(rows + ro[i] * row_floats, rows + (ro[i] + kept[i]) * row_floats);
-            if (has_vad) vad_out[i].assign(vad.begin() + ro[i], vad.begin() + ro[i + 1]);
-        }
-    ctu_host_free(arena);
-    ctu_host_free(rows);
-    ctu_plan_destroy(plan);
-}
-
-// -format_out raw|wave: one shard through ctu_engine_run_signal_host, samples per utterance back in `out`
-void run_shard_signal(ctu_engine *eng, const std::vector<const std::vector<int16_t> *> &utts, std::vector<std::vector<int16_t>> &out,
-                      std::string &err) {
-    std::vector<int64_t> ns;
-    for (auto *u : utts) ns.push_back((int64_t)u->size());
-    ctu_plan *plan = nullptr;
-    if (ctu_plan_create(eng, ns.data(), (int)ns.size(), &plan) != CTU_OK) {
-        err = ctu_last_error(eng);
-        return;
-    }
-    const int64_t *so = ctu_plan_sample_offsets(plan), *no = ctu_plan_out_samples(plan);
-    std::vector<int16_t> arena((size_t)ctu_plan_total_samples(plan), 0), res(arena.size(), 0);
-    for (size_t i = 0; i < utts.size(); i++) std::copy(utts[i]->begin(), utts[i]->end(), arena.begin() + so[i]);
-    if (ctu_engine_run_signal_host(eng, plan, arena.data(), res.data()) != CTU_OK) err = ctu_last_error(eng);
-    else
-        for (size_t i = 0; i < utts.size(); i++) out[i].assign(res.begin() + so[i], res.begin() + so[i] + no[i]);
-    ctu_plan_destroy(plan);
-}
-
 // rawOUT::write (src/io/out.cc:493-499): int16 samples, byte-swapped for -endian_out big
-void write_raw(const std::string &path, const std::vector<int16_t> &x, bool big) {
-    std::vector<uint8_t> b;
-    b.reserve(x.size() * 2);
-    for (int16_t v : x) put16(b, (uint16_t)v, big);
-    write_file(path, b, "OUT: Cannot open output stream!");
+void write_raw(const std::string &path, const int16_t *x, size_t n, bool big) {
+    File f(std::fopen(path.c_str(), "wb"));
+    if (!f) throw Fatal("OUT: Cannot open output stream!");
+    bool ok;
+    if (!big) ok = n == 0 || std::fwrite(x, 2, n, f.get()) == n;
+    else {
+        std::vector<uint16_t> sw(n);
+        for (size_t i = 0; i < n; i++) sw[i] = __builtin_bswap16((uint16_t)x[i]);
+        ok = n == 0 || std::fwrite(sw.data(), 2, n, f.get()) == n;
+    }
+    if (!ok) throw Fatal("OUT: Error in stream writing!");
 }
 
 // waveOUT (src/io/out.cc:517-564): canonical 44-byte RIFF header, sizes patched at close, samples in host order
-void write_wave(const std::string &path, const std::vector<int16_t> &x, int fs) {
+void write_wave(const std::string &path, const int16_t *x, size_t n, int fs) {
     std::vector<uint8_t> b;
-    b.reserve(44 + x.size() * 2);
-    const uint32_t data = (uint32_t)(2 * x.size());
+    const uint32_t data = (uint32_t)(2 * n);
     for (char c : std::string("RIFF")) b.push_back((uint8_t)c);
     put32(b, data + 36, false);
     for (char c : std::string("WAVEfmt ")) b.push_back((uint8_t)c);
@@ -297,8 +295,166 @@ void write_wave(const std::string &path, const std::vector<int16_t> &x, int fs) 
     put16(b, 16, false);
     for (char c : std::string("data")) b.push_back((uint8_t)c);
     put32(b, data, false);
-    for (int16_t v : x) put16(b, (uint16_t)v, false);
-    write_file(path, b, "OUT: Cannot open data file!");
+    File f(std::fopen(path.c_str(), "wb"));
+    if (!f) throw Fatal("OUT: Cannot open data file!");
+    if (std::fwrite(b.data(), 1, b.size(), f.get()) != b.size() || (n && std::fwrite(x, 2, n, f.get()) != n)) throw Fatal("OUT: Error in stream writing!");
+}
+
+// ---------------------------------------------------------------- the pipeline's plumbing
+// bounded hand-over between two stages; close() wakes everybody up (end of the list, or a stage gave up)
+template <class T>
+struct Chan {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<T> q;
+    size_t cap;
+    bool closed = false;
+    explicit Chan(size_t c) : cap(c) {}
+    bool push(T v) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return q.size() < cap || closed; });
+        if (closed) return false;
+        q.push_back(std::move(v));
+        cv.notify_all();
+        return true;
+    }
+    bool pop(T &v) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> l(m);
+        closed = true;
+        cv.notify_all();
+    }
+};
+
+// fn(i) for i in [0, n) on up to `threads` threads; the exception of the lowest failing index is rethrown (what a
+// sequential loop would have hit first)
+template <class F>
+void parallel_for(int threads, size_t n, F fn) {
+    if (n == 0) return;
+    const int nt = (int)std::min<size_t>((size_t)std::max(threads, 1), n);
+    std::atomic<size_t> next{0};
+    std::mutex em;
+    size_t err_at = n;
+    std::exception_ptr err;
+    auto body = [&] {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) return;
+            try {
+                fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> l(em);
+                if (i < err_at) {
+                    err_at = i;
+                    err = std::current_exception();
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// page-locked buffers are expensive to make (the runtime pins every page): they go round between the batches
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+struct PinPool {
+    std::mutex m;
+    std::vector<PinBuf> idle;
+    PinBuf get(size_t bytes) {
+        bytes = std::max<size_t>(bytes, 4096);
+        {
+            std::lock_guard<std::mutex> l(m);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].cap >= bytes && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+            if (best < idle.size()) {
+                PinBuf b = idle[best];
+                idle.erase(idle.begin() + best);
+                return b;
+            }
+            if (!idle.empty()) {  // nothing fits: trade the smallest idle one in
+                size_t sm = 0;
+                for (size_t i = 1; i < idle.size(); i++)
+                    if (idle[i].cap < idle[sm].cap) sm = i;
+                ctu_host_free(idle[sm].p);
+                idle.erase(idle.begin() + sm);
+            }
+        }
+        PinBuf b;
+        b.cap = bytes + bytes / 8;
+        b.p = ctu_host_alloc(b.cap);
+        if (!b.p) throw Fatal("ENGINE: cannot allocate page-locked host memory");
+        return b;
+    }
+    void put(PinBuf b) {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> l(m);
+        idle.push_back(b);
+    }
+    ~PinPool() {
+        for (auto &b : idle) ctu_host_free(b.p);
+    }
+};
+
+// one GPU's part of a batch
+struct Shard {
+    std::vector<size_t> idx;      // positions in the batch, list order
+    std::vector<int64_t> ns, so;  // samples per utterance, arena offsets (ctu_arena_layout)
+    int64_t total_samples = 0, total_frames = 0;
+    PinBuf arena, rows;           // int16 in; float32 rows (or int16 samples with -format_out raw|wave) out
+    std::vector<int64_t> ro, kept, nout;
+    std::vector<uint8_t> vad;
+};
+struct Batch {
+    size_t pos = 0, n = 0;                        // items [pos, pos + n)
+    std::vector<Shard> sh;                        // one per GPU
+    std::vector<std::pair<int, size_t>> where;    // item -> (gpu, position in its shard)
+    std::exception_ptr err;                       // the reader failed on this batch: rethrown once the earlier ones are through
+};
+
+// the engine's part of a shard: plan over its lengths, H2D + kernels + D2H from / to the page-locked buffers
+void run_shard(ctu_engine *eng, Shard &sh, PinPool &pool, bool signal_out, bool has_vad, int row_floats) {
+    ctu_plan *plan = nullptr;
+    if (ctu_plan_create(eng, sh.ns.data(), (int)sh.ns.size(), &plan) != CTU_OK) throw Fatal(ctu_last_error(eng));
+    struct PlanGuard {
+        ctu_plan *p;
+        ~PlanGuard() { ctu_plan_destroy(p); }
+    } guard{plan};
+    const size_t n = sh.ns.size();
+    const int64_t *so = ctu_plan_sample_offsets(plan), *ro = ctu_plan_row_offsets(plan);
+    if (ctu_plan_total_samples(plan) != sh.total_samples || !std::equal(sh.so.begin(), sh.so.end(), so))
+        throw Fatal("ENGINE: internal: the plan's arena layout differs from ctu_arena_layout");
+    sh.total_frames = ctu_plan_total_frames(plan);
+    sh.ro.assign(ro, ro + n + 1);
+    sh.kept.assign(n, 0);
+    if (signal_out) {  // -format_out raw|wave: samples at the utterances' own offsets (ctu_engine_run_signal_host)
+        sh.rows = pool.get((size_t)sh.total_samples * sizeof(int16_t));
+        const int64_t *no = ctu_plan_out_samples(plan);
+        sh.nout.assign(no, no + n);
+        if (ctu_engine_run_signal_host(eng, plan, static_cast<const int16_t *>(sh.arena.p), static_cast<int16_t *>(sh.rows.p)) != CTU_OK)
+            throw Fatal(ctu_last_error(eng));
+        return;
+    }
+    sh.rows = pool.get((size_t)sh.total_frames * row_floats * sizeof(float));
+    sh.vad.assign(has_vad ? (size_t)sh.total_frames : 0, 0);
+    // rows_per_utt < frames only with -vad_apply_mode drop (rows compacted in place by the library)
+    if (ctu_engine_run_host(eng, plan, static_cast<const int16_t *>(sh.arena.p), static_cast<float *>(sh.rows.p), has_vad ? sh.vad.data() : nullptr,
+                            sh.kept.data()) != CTU_OK)
+        throw Fatal(ctu_last_error(eng));
 }
 
 int real_main(int argc, char **argv) {
@@ -306,14 +462,28 @@ int real_main(int argc, char **argv) {
     int ngpu = 1;
     std::vector<int> gpu_map;  // --gpu-map a,b,...: device ordinal of every engine (default 0 .. N-1); an ordinal may repeat, which puts
                                // several engines on one device - the multi-engine host path rehearsed on a box with fewer GPUs
+    int io_threads = 0;     // --io-threads N: file readers (default: the hardware threads, at most 16)
+    int write_threads = 0;  // --write-threads N: file writers (default 1: creating files in one directory does not scale)
+    int batch_mib = 256;    // --batch-mib M: PCM per batch
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) ngpu = std::max(1, std::atoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--io-threads") && i + 1 < argc) io_threads = std::max(1, std::atoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--write-threads") && i + 1 < argc) write_threads = std::max(1, std::atoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--batch-mib") && i + 1 < argc) batch_mib = std::max(1, std::atoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--gpu-map") && i + 1 < argc) {
             std::istringstream ms(argv[++i]);
             std::string tok;
             while (std::getline(ms, tok, ',')) gpu_map.push_back(std::atoi(tok.c_str()));
         }
         else args.emplace_back(argv[i]);
+    }
+    if (io_threads == 0) {
+        const char *ev = std::getenv("CTU_IO_THREADS");
+        io_threads = ev ? std::max(1, std::atoi(ev)) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    if (write_threads == 0) {
+        const char *ev = std::getenv("CTU_WRITE_THREADS");
+        write_threads = ev ? std::max(1, std::atoi(ev)) : 1;
     }
     if (!gpu_map.empty() && (int)gpu_map.size() != ngpu) throw Fatal("ENGINE: --gpu-map needs one device ordinal per engine of --gpus");
     ctu::Opts o;
@@ -399,99 +569,227 @@ int real_main(int argc, char **argv) {
     std::vector<std::vector<float>> all_rows(cmvn ? items.size() : 0);
     std::vector<int64_t> all_ns(cmvn ? items.size() : 0);
 
-    const size_t batch_samples = 512u << 20;  // ~1 GiB of PCM per batch
-    size_t pos = 0;
-    while (pos < items.size()) {
-        std::vector<std::vector<int16_t>> pcm;
-        size_t total = 0, end = pos;
-        while (end < items.size() && (total < batch_samples || end == pos)) {
-            pcm.push_back(decode(o, items[end].fin));
-            if (ctu_num_frames(gpus[0].eng, (int64_t)pcm.back().size()) < 0) throw Fatal("IO: Signal shorter than one frame!");
-            total += pcm.back().size();
-            end++;
-        }
-        const size_t n = end - pos;
-        // longest-processing-time sharding over the GPUs by frame count
-        std::vector<size_t> order(n);
-        for (size_t i = 0; i < n; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pcm[a].size() > pcm[b].size(); });
-        std::vector<std::vector<size_t>> shard(ngpu);
-        std::vector<size_t> load(ngpu, 0);
-        for (size_t i : order) {
-            const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            shard[g].push_back(i);
-            load[g] += pcm[i].size();
-        }
-        for (auto &sh : shard) std::sort(sh.begin(), sh.end());  // list order inside a shard
-        if (signal_out) {  // speech enhancement: samples instead of rows (src/io/batch.cc:62-65,223-227)
-            std::vector<std::vector<int16_t>> wav(n);
-            std::vector<std::string> errs(ngpu);
-            std::vector<std::thread> th;
-            for (int g = 0; g < ngpu; g++)
-                th.emplace_back([&, g] {
-                    std::vector<const std::vector<int16_t> *> u;
-                    std::vector<std::vector<int16_t>> out(shard[g].size());
-                    for (size_t i : shard[g]) u.push_back(&pcm[i]);
-                    if (!u.empty()) run_shard_signal(gpus[g].eng, u, out, errs[g]);
-                    for (size_t k = 0; k < shard[g].size(); k++) wav[shard[g][k]] = std::move(out[k]);
-                });
-            for (auto &t : th) t.join();
-            for (auto &e : errs)
-                if (!e.empty()) throw Fatal(e);
-            for (size_t i = 0; i < n; i++) {
-                const Item &it = items[pos + i];
-                if (o.verbose) std::fprintf(stderr, "processing: %s - %lld frames.\n", it.fin.c_str(),
-                                            (long long)ctu_num_frames(gpus[0].eng, (int64_t)pcm[i].size()));
-                if (o.format_out == "raw") write_raw(it.fout, wav[i], d.swap_out != 0);
-                else write_wave(it.fout, wav[i], o.fs);
-            }
-            pos = end;
-            continue;
-        }
-        std::vector<std::vector<float>> rows(n);
-        std::vector<std::string> vads(n);
-        std::vector<std::string> errs(ngpu);
-        std::vector<std::thread> th;
-        for (int g = 0; g < ngpu; g++)
-            th.emplace_back([&, g] {
-                std::vector<const std::vector<int16_t> *> u;
-                std::vector<std::vector<float>> out(shard[g].size());
-                std::vector<std::string> vout(shard[g].size());
-                for (size_t i : shard[g]) u.push_back(&pcm[i]);
-                if (!u.empty()) run_shard(gpus[g].eng, u, out, vout, d.has_vad != 0, d.row_floats, errs[g]);
-                for (size_t k = 0; k < shard[g].size(); k++) {
-                    rows[shard[g][k]] = std::move(out[k]);
-                    vads[shard[g][k]] = std::move(vout[k]);
+    // ---- the pipeline: reader -> engines (this thread) -> writer, one batch in each at a time
+    const size_t batch_samples = (size_t)batch_mib << 19;  // samples of PCM per batch (default 1 GiB)
+    PinPool pool;
+    // CTU_HOST_TIMING=1: seconds each stage was busy (not waiting for its neighbours), on stderr at the end
+    const bool timing = std::getenv("CTU_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_read = 0, t_engine = 0, t_write = 0;
+    const double t_loop0 = now();
+    Chan<std::unique_ptr<Batch>> to_engine(1), to_writer(1);
+    std::atomic<bool> giving_up{false};
+
+    std::thread reader([&] {
+        size_t pos = 0;
+        while (pos < items.size() && !giving_up) {
+            std::unique_ptr<Batch> b(new Batch);
+            b->pos = pos;
+            const double t0 = now();
+            try {
+                // sizes first (stat, WAVE headers), in groups, until the batch is full
+                std::vector<int64_t> ns;
+                size_t total = 0, end = pos;
+                bool stop = false;
+                while (!stop && end < items.size() && (total < batch_samples || end == pos)) {
+                    const size_t group = std::min<size_t>(items.size() - end, 1024);
+                    std::vector<int64_t> g(group);
+                    std::vector<std::exception_ptr> gerr(group);
+                    parallel_for(io_threads, group, [&](size_t i) {
+                        try {
+                            g[i] = probe_samples(o, items[end + i].fin);
+                            if (ctu_num_frames(gpus[0].eng, g[i]) < 0) throw Fatal("IO: Signal shorter than one frame!");
+                        } catch (...) {
+                            gerr[i] = std::current_exception();
+                        }
+                    });
+                    for (size_t i = 0; i < group && (total < batch_samples || end == pos); i++, end++) {
+                        if (gerr[i]) {  // a bad file ends the batch in front of it; it fails the batch it would start
+                            if (end == pos) std::rethrow_exception(gerr[i]);
+                            stop = true;
+                            break;
+                        }
+                        ns.push_back(g[i]);
+                        total += (size_t)g[i];
+                    }
                 }
-            });
-        for (auto &t : th) t.join();
-        for (auto &e : errs)
-            if (!e.empty()) throw Fatal(e);
-        for (size_t i = 0; i < n; i++) {
-            const Item &it = items[pos + i];
-            const int64_t nr = (int64_t)rows[i].size() / d.row_floats;
-            if (o.verbose) std::fprintf(stderr, "processing: %s - %lld frames.\n", it.fin.c_str(), (long long)nr);
-            if (cmvn) {  // rows wait for the corpus statistics
-                all_rows[pos + i] = std::move(rows[i]);
-                all_ns[pos + i] = (int64_t)pcm[i].size();
-                continue;
+                const size_t n = b->n = end - pos;
+                // longest-processing-time sharding over the GPUs by length; list order inside a shard
+                std::vector<size_t> order(n);
+                for (size_t i = 0; i < n; i++) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ns[x] > ns[y]; });
+                b->sh.resize(ngpu);
+                std::vector<size_t> load(ngpu, 0);
+                for (size_t i : order) {
+                    const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                    b->sh[g].idx.push_back(i);
+                    load[g] += (size_t)ns[i];
+                }
+                b->where.resize(n);
+                for (int g = 0; g < ngpu; g++) {
+                    Shard &sh = b->sh[g];
+                    std::sort(sh.idx.begin(), sh.idx.end());
+                    for (size_t k = 0; k < sh.idx.size(); k++) {
+                        sh.ns.push_back(ns[sh.idx[k]]);
+                        b->where[sh.idx[k]] = {g, k};
+                    }
+                    sh.so.resize(sh.ns.size() + 1);
+                    sh.total_samples = ctu_arena_layout(sh.ns.data(), (int)sh.ns.size(), sh.so.data());
+                    if (sh.idx.empty()) continue;
+                    // the bytes between utterances are read under zero weights and need no particular value (include/ctu_engine.h)
+                    sh.arena = pool.get((size_t)sh.total_samples * sizeof(int16_t));
+                }
+                parallel_for(io_threads, n, [&](size_t i) {
+                    Shard &sh = b->sh[b->where[i].first];
+                    const size_t k = b->where[i].second;
+                    decode_into(o, items[pos + i].fin, static_cast<int16_t *>(sh.arena.p) + sh.so[k], (size_t)sh.ns[k]);
+                });
+                pos = end;
+                t_read += now() - t0;
+            } catch (...) {
+                b->err = std::current_exception();
+                to_engine.push(std::move(b));
+                break;
             }
-            if (d.has_vad && o.vad_out_mode != "none") {  // one ASCII '0'/'1' per frame (src/vad/vad.h:67-70)
-                if (it.fvad.empty()) throw Fatal("VAD::new_file(): invalid filename!");
-                write_file(it.fvad, std::vector<uint8_t>(vads[i].begin(), vads[i].end()), "FileWriter: cannot open file!");
-            }
-            if (ark) ark->add(it.fout, rows[i].data(), nr, d.row_floats);
-            else if (pf) pf->add(rows[i].data(), nr, d.row_floats);
-            else {
-                // -fea_trap: the reference's writers overwrite fea_kind with "spec" when they save their first frame
-                // (src/io/out.cc:182), so every header after the first file carries base kind 8 (out.cc:146-152).
-                ctu_dims dh = d;
-                if (o.fea_trap && pos + i > 0) dh.htk_kind = (d.htk_kind & ~077) | 8;
-                write_htk(it.fout, rows[i].data(), nr, dh);
-            }
+            if (!to_engine.push(std::move(b))) break;
         }
-        pos = end;
+        to_engine.close();
+    });
+
+    std::exception_ptr writer_err;
+    std::thread writer([&] {
+        std::unique_ptr<Batch> b;
+        while (to_writer.pop(b)) {
+            const double t0 = now();
+            try {
+                const size_t n = b->n;
+                auto rows_of = [&](size_t i, int64_t &nr) {
+                    const Shard &sh = b->sh[b->where[i].first];
+                    const size_t k = b->where[i].second;
+                    nr = sh.kept[k];
+                    return static_cast<const float *>(sh.rows.p) + sh.ro[k] * d.row_floats;
+                };
+                if (o.verbose)
+                    for (size_t i = 0; i < n; i++) {
+                        const Shard &sh = b->sh[b->where[i].first];
+                        const size_t k = b->where[i].second;
+                        std::fprintf(stderr, "processing: %s - %lld frames.\n", items[b->pos + i].fin.c_str(),
+                                     (long long)(signal_out ? sh.ro[k + 1] - sh.ro[k] : sh.kept[k]));
+                    }
+                if (signal_out) {  // speech enhancement: samples instead of rows (src/io/batch.cc:62-65,223-227)
+                    parallel_for(write_threads, n, [&](size_t i) {
+                        const Shard &sh = b->sh[b->where[i].first];
+                        const size_t k = b->where[i].second;
+                        const int16_t *x = static_cast<const int16_t *>(sh.rows.p) + sh.so[k];
+                        if (o.format_out == "raw") write_raw(items[b->pos + i].fout, x, (size_t)sh.nout[k], d.swap_out != 0);
+                        else write_wave(items[b->pos + i].fout, x, (size_t)sh.nout[k], o.fs);
+                    });
+                } else if (cmvn) {  // rows wait for the corpus statistics
+                    for (size_t i = 0; i < n; i++) {
+                        int64_t nr;
+                        const float *r = rows_of(i, nr);
+                        all_rows[b->pos + i].assign(r, r + nr * d.row_floats);
+                        const Shard &sh = b->sh[b->where[i].first];
+                        all_ns[b->pos + i] = sh.ns[b->where[i].second];
+                    }
+                } else {
+                    const bool vad_files = d.has_vad && o.vad_out_mode != "none";
+                    if (vad_files)
+                        for (size_t i = 0; i < n; i++)
+                            if (items[b->pos + i].fvad.empty()) throw Fatal("VAD::new_file(): invalid filename!");
+                    const bool per_file = !ark && !pf;
+                    parallel_for(write_threads, n, [&](size_t i) {
+                        const Item &it = items[b->pos + i];
+                        const Shard &sh = b->sh[b->where[i].first];
+                        const size_t k = b->where[i].second;
+                        if (vad_files) {  // one ASCII '0'/'1' per frame (src/vad/vad.h:67-70)
+                            std::vector<uint8_t> v(sh.vad.begin() + sh.ro[k], sh.vad.begin() + sh.ro[k + 1]);
+                            write_file(it.fvad, v, "FileWriter: cannot open file!");
+                        }
+                        if (per_file) {
+                            // -fea_trap: the reference's writers overwrite fea_kind with "spec" when they save their first frame
+                            // (src/io/out.cc:182), so every header after the first file carries base kind 8 (out.cc:146-152).
+                            ctu_dims dh = d;
+                            if (o.fea_trap && b->pos + i > 0) dh.htk_kind = (d.htk_kind & ~077) | 8;
+                            int64_t nr;
+                            const float *r = rows_of(i, nr);
+                            write_htk(it.fout, r, nr, dh);
+                        }
+                    });
+                    if (!per_file)
+                        for (size_t i = 0; i < n; i++) {
+                            int64_t nr;
+                            const float *r = rows_of(i, nr);
+                            if (ark) ark->add(items[b->pos + i].fout, r, nr, d.row_floats);
+                            else pf->add(r, nr, d.row_floats);
+                        }
+                }
+            } catch (...) {
+                writer_err = std::current_exception();
+                giving_up = true;
+            }
+            for (auto &sh : b->sh) {
+                pool.put(sh.arena);
+                pool.put(sh.rows);
+            }
+            b.reset();
+            t_write += now() - t0;
+            if (writer_err) break;
+        }
+        to_writer.close();  // a failed writer must not leave the engines waiting to hand over
+    });
+
+    std::exception_ptr engine_err;
+    {
+        std::unique_ptr<Batch> b;
+        while (!engine_err && to_engine.pop(b)) {
+            if (b->err) {
+                engine_err = b->err;
+                break;
+            }
+            const double t0 = now();
+            try {
+                std::vector<std::exception_ptr> errs(ngpu);
+                std::vector<std::thread> th;
+                for (int g = 0; g < ngpu; g++)
+                    th.emplace_back([&, g] {
+                        try {
+                            if (!b->sh[g].idx.empty()) run_shard(gpus[g].eng, b->sh[g], pool, signal_out, d.has_vad != 0, d.row_floats);
+                        } catch (...) {
+                            errs[g] = std::current_exception();
+                        }
+                    });
+                for (auto &t : th) t.join();
+                for (auto &e : errs)
+                    if (e) std::rethrow_exception(e);
+            } catch (...) {
+                engine_err = std::current_exception();
+                for (auto &sh : b->sh) {
+                    pool.put(sh.arena);
+                    pool.put(sh.rows);
+                }
+                break;
+            }
+            t_engine += now() - t0;
+            if (!to_writer.push(std::move(b))) break;
+        }
     }
+    giving_up = giving_up || (bool)engine_err;
+    to_engine.close();
+    {   // a reader blocked on a full hand-over sees the close; batches it had queued go back to the pool
+        std::unique_ptr<Batch> b;
+        while (to_engine.pop(b))
+            for (auto &sh : b->sh) pool.put(sh.arena);
+    }
+    reader.join();
+    to_writer.close();
+    writer.join();
+    if (timing)
+        std::fprintf(stderr, "host stages busy: reader %.3f s, engines %.3f s, writer %.3f s; loop %.3f s, %d + %d I/O threads, %d engine(s)\n", t_read, t_engine,
+                     t_write, now() - t_loop0, io_threads, write_threads, ngpu);
+    if (writer_err) std::rethrow_exception(writer_err);
+    if (engine_err) std::rethrow_exception(engine_err);
+
     if (cmvn) {
         // speaker table in order of first appearance (cmvn_POST::add_spk, src/fea/post_impl.cc:120-142)
         std::vector<std::string> spk_names;

@@ -89,6 +89,11 @@ int64_t ctu_num_frames(const ctu_engine *, int64_t nsamples);
  * ctu_plan_total_samples() must be readable, its contents between utterances do not matter).  Its output rows start at row ctu_plan_row_offsets()[i].  Both offset arrays
  * have n_utt+1 entries and stay valid until ctu_plan_destroy. */
 int ctu_plan_create(ctu_engine *, const int64_t *utt_nsamples, int32_t n_utt, ctu_plan **out);
+/* The arena layout rule of ctu_plan_create on its own (no engine, no device): writes the n_utt+1 sample offsets a plan over
+ * these lengths will report (sample_off may be NULL) and returns its ctu_plan_total_samples(), or a negative error code.  A host
+ * loop that reads files straight into a page-locked arena (the counterpart of rawIN::loadframe, src/io/in.cc:434-460) lays the
+ * next batch out with it while the engine is busy with the current one. */
+int64_t ctu_arena_layout(const int64_t *utt_nsamples, int32_t n_utt, int64_t *sample_off);
 void ctu_plan_destroy(ctu_plan *);
 const int64_t *ctu_plan_sample_offsets(const ctu_plan *);
 const int64_t *ctu_plan_row_offsets(const ctu_plan *);

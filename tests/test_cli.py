@@ -384,3 +384,62 @@ def test_spectral_subtraction_list_is_one_chain(tmp_path):
             e = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
             rn = np.abs(got - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1.0)
             assert e.max() <= 1e-3 and rn.max() <= 1e-4, (i, float(e.max()), float(rn.max()))   # the conditioning class of an NR configuration
+
+
+def _many_files(tmp_path, n, seed=7):
+    """n short raw files (1 .. 4 s of 16 kHz noise: a dozen to the MiB) and a list that sends their rows to <tmp>/o/"""
+    rng = np.random.default_rng(seed)
+    (tmp_path / "i").mkdir()
+    (tmp_path / "o").mkdir()
+    lines = []
+    for k in range(n):
+        x = (rng.standard_normal(int(rng.integers(16000, 64000))) * 2000).astype("<i2")
+        x.tofile(tmp_path / "i" / ("f%03d.raw" % k))
+        lines.append("%s %s" % (tmp_path / "i" / ("f%03d.raw" % k), tmp_path / "o" / ("f%03d.htk" % k)))
+    (tmp_path / "list.scp").write_text("\n".join(lines) + "\n")
+    return str(tmp_path / "list.scp")
+
+
+@pytest.mark.gpu
+def test_pipelined_host_loop_is_independent_of_batching_and_threads(tmp_path):
+    """The three-stage host loop (reader / engines / writer, main.cc): whatever the batch size and the thread counts, the
+    files come out byte for byte the same - many small batches exercise every hand-over and the page-locked buffer pool."""
+    lst = _many_files(tmp_path, 60)
+    base = "-fs 16000 -format_in raw -format_out htk -preset mfcc -S".split() + [lst]
+    r = run(base + ["--io-threads", "1", "--write-threads", "1"])
+    assert r.returncode == 0, r.stderr
+    want = {f: (tmp_path / "o" / f).read_bytes() for f in sorted(os.listdir(tmp_path / "o"))}
+    assert len(want) == 60
+    for extra in (["--batch-mib", "1"], ["--batch-mib", "1", "--io-threads", "8", "--write-threads", "3"], ["--gpus", "2", "--gpu-map", "0,0", "--batch-mib", "1"]):
+        for f in want:
+            os.unlink(tmp_path / "o" / f)
+        r = run(base + extra)
+        assert r.returncode == 0, r.stderr
+        got = {f: (tmp_path / "o" / f).read_bytes() for f in sorted(os.listdir(tmp_path / "o"))}
+        assert got.keys() == want.keys() and all(got[f] == want[f] for f in want), extra
+    # ark / scp through the ordered writer: entries in list order whatever the batching
+    for extra in ([], ["--batch-mib", "1", "--io-threads", "8"]):
+        r = run("-fs 16000 -format_in raw -preset mfcc -format_out".split() + ["ark=" + str(tmp_path / ("a%d.ark" % len(extra))), "-S", lst] + extra)
+        assert r.returncode == 0, r.stderr
+    a0, a1 = (tmp_path / "a0.ark").read_bytes(), (tmp_path / "a4.ark").read_bytes()
+    assert a0 == a1 and len(a0) > 60 * 13 * 4 * 28
+    assert (tmp_path / "a0.scp").read_text().replace("a0.ark", "a4.ark") == (tmp_path / "a4.scp").read_text()
+    keys = [l.split()[0] for l in (tmp_path / "a0.scp").read_text().splitlines()]
+    assert keys == [str(tmp_path / "o" / ("f%03d.htk" % k)) for k in range(60)]
+
+
+@pytest.mark.gpu
+def test_a_bad_file_stops_the_list_after_the_batches_in_front_of_it(tmp_path):
+    """The reference aborts the batch at the first bad file with its message and exit status -1, having written the files in
+    front of it (src/main.cpp:54-60, src/io/batch.cc:326-421).  The pipelined loop writes every batch that lies wholly in
+    front of the bad file and nothing behind it."""
+    lst = _many_files(tmp_path, 40)
+    os.unlink(tmp_path / "i" / "f025.raw")
+    r = run("-fs 16000 -format_in raw -format_out htk -preset mfcc -S".split() + [lst, "--batch-mib", "1", "--io-threads", "4"])
+    assert r.returncode == 255 and "Cannot open data file" in r.stderr
+    done = sorted(os.listdir(tmp_path / "o"))
+    assert done == ["f%03d.htk" % k for k in range(len(done))] and 0 < len(done) <= 25
+    # a file too short for one frame: the reference's text (src/io/in.cc:277)
+    np.zeros(100, dtype="<i2").tofile(tmp_path / "i" / "f025.raw")
+    r = run("-fs 16000 -format_in raw -format_out htk -preset mfcc -S".split() + [lst, "--batch-mib", "1"])
+    assert r.returncode == 255 and "Signal shorter than one frame" in r.stderr
