@@ -317,7 +317,17 @@ bool vf_eligible(const ctu::Design &d) {
     return CTU_VF && CTU_MD && plain_cepstral(d) && o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc" &&
            fused_frame_shape(d) && o.vad_lpc_coefs == VF_NC && d.post_order == 0;
 }
-bool md_eligible(const ctu::Design &d) { return CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d)); }
+// the compressed-band LP chain (PLP and friends: -fb_inld, at most 16 lags, no energy column, no NR, no VAD): its cosine iDFT
+// (src/fea/fea_impl.cc:181-198) is the same contraction over the bands as the DCT and takes the same MFMA tail
+#ifndef CTU_LP_MD
+#define CTU_LP_MD 1  // 0: the lags on the VALU (cell_accumulate + cells_reduce), for A/B
+#endif
+bool lp_md_eligible(const ctu::Design &d) {
+    const ctu::Opts &o = d.o;
+    return CTU_MD && CTU_LP_MD && (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) && o.fb_inld && o.fea_lporder + 1 <= 16 && !o.nr_when_afterFB && !o.fea_E &&
+           o.fb_power && o.remove_dc && !o.remove_dc1 && !d.signal_out && !o.do_vad() && o.nr_mode == "none";
+}
+bool md_eligible(const ctu::Design &d) { return (CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d))) || lp_md_eligible(d); }
 // hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 25 ms frames at 8 or 16 kHz, the
 // presets' 12 cepstral coefficients for the detector, the plain chain into cepstra or band energies
 int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode == "fwss" ? 2 : o.nr_mode == "2fwss" ? 3 : 0; }
@@ -472,8 +482,8 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
     if (!t.md) ft.insert(ft.end(), cf.begin(), cf.end());  // the MFMA tail reads the am table below instead
     while (ft.size() & 3) ft.push_back(0.f);
     if (t.md) {
-        // A operands of the DCT MFMAs: for slot sl and half h, lane m + 16 kk holds row m of the folded DCT table at the
-        // band of cell (sl, group kk + 4 h); zero for idle cells and for rows >= the number of output slots
+        // A operands of the DCT MFMAs: for slot sl and half h, lane m + 16 kk holds row m of the folded DCT table (LP chain: of
+        // the cosine iDFT table) at the band of cell (sl, group kk + 4 h); zero for idle cells and for rows >= the number of output slots
         t.am_off = (int)ft.size();
         for (int sl = 0; sl < NS; sl++)
             for (int h = 0; h < 2; h++)
@@ -481,7 +491,9 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
                     const int m = lane & 15, g = (lane >> 4) + 4 * h;
                     const int b = cell[(sl * 8 + g) * 2 + 1];
                     float v = 0.f;
-                    if (b >= 0 && m < t.ncoef_out && coef_of_slot[m] >= 0) v = (float)(*coef_tab)[(size_t)coef_of_slot[m] * B + b];
+                    if (d.kind == ctu::FeaKind::Dctc) {
+                        if (b >= 0 && m < t.ncoef_out && coef_of_slot[m] >= 0) v = (float)(*coef_tab)[(size_t)coef_of_slot[m] * B + b];
+                    } else if (b >= 0 && m < ncoef) v = (float)(*coef_tab)[(size_t)m * B + b];  // LP: row m = lag m
                     ft.push_back(v);
                 }
     }
@@ -846,6 +858,11 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
             if (kp.nr_exten) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_EXTEN, 0, true, true>, grid, s, kp);
             else launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, true>, grid, s, kp);
         }
+    }
+    else if (e->md && feat == FEAT_LP) {  // the compressed-band LP chain: lags by the MFMA tail, the recursions in lp_tail_kernel
+        if (!(base && kp.fb_inld && !kp.nr_exten && narrow)) throw std::runtime_error("internal: MD tables without the MD instantiation");
+        if (kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 12, true>, grid, s, kp);
+        else launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_INLD, 0, true>, grid, s, kp);
     }
     else if (e->md) {
         if (!(base && !kp.fb_inld && feat == FEAT_DCTC && narrow)) throw std::runtime_error("internal: MD tables without the MD instantiation");

@@ -50,7 +50,8 @@ namespace {
 //         MAX_LP.  The unrolled Levinson / a->c tail then has no guards and no dead orders.
 // MD:     the DCT-II tail of phase 2 on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains): the band
 //         logarithms of a slot are the B operand as they stand (lane = frame + 8 h + 16 kk holds band group kk + 4 h),
-//         the folded DCT table is the A operand; FEAT_DCTC with NC = 16 only.
+//         the folded DCT table is the A operand; FEAT_DCTC with NC = 16, and FEAT_LP with NC = 16 (compressed bands,
+//         the cosine iDFT table as A: the lags of the LP analysis are the same kind of contraction over the bands).
 //
 // Work distribution.  A tile is <= 64 consecutive frames of one utterance.  Stateless chains: the eight waves of a
 // workgroup share each tile (wave w takes frame slots 8w..8w+7).  Per-wave chains (p.per_wave; exten): every wave
@@ -80,7 +81,7 @@ constexpr int fe_waves_per_simd(int mode, bool vf, bool ss, bool sy = false) {
 template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false, bool SY = false>
 __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
-    static_assert(!MD || (FEAT == FEAT_DCTC && NC == 16), "MD: DCT tail with 16 coefficient rows");
+    static_assert(!MD || ((FEAT == FEAT_DCTC || FEAT == FEAT_LP) && NC == 16), "MD: DCT / cosine-iDFT tail with 16 coefficient rows");
     static_assert(!VF || !VX, "VF: no spectrum export");
     static_assert(!SS || (!VX && !VF && GEN == GEN_PLAIN), "SS: plain chain");
     static_assert(!((VF || SS) && MODE == 0) || NZ == 13, "VF / SS in the 512-point mode: 400-sample windows (16 lanes x 25 samples)");
@@ -1018,11 +1019,23 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 float o4[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) o4[r] = acc0[r] + dpp_mov<0x128>(acc1[r]);  // row_ror:8 brings column n + 8
-                float *orow = p.rows + (rbase + fslot) * p.D + 4 * (lane >> 4);
-                if (fvalid && (lane & 8) == 0) {
+                if constexpr (FEAT == FEAT_LP) {
+                    // rows of the table = lags of the cosine iDFT (src/fea/fea_impl.cc:181-198): lags 4j .. 4j+3 go to the frame's
+                    // scratch row for lp_tail_kernel (Levinson-Durbin and a -> c, one frame per lane)
+                    const int P_ = LPO ? LPO : p.lporder;
+                    float *rrow = reinterpret_cast<float *>(p.lp_r) + (rbase + fslot) * p.lp_stride + 4 * (lane >> 4);
+                    if (fvalid && (lane & 8) == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (4 * (lane >> 4) + r < p.ncoef_out) orow[r] = o4[r];
+                        for (int r = 0; r < 4; r++)
+                            if (4 * (lane >> 4) + r <= P_) rrow[r] = o4[r];
+                    }
+                } else {
+                    float *orow = p.rows + (rbase + fslot) * p.D + 4 * (lane >> 4);
+                    if (fvalid && (lane & 8) == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (4 * (lane >> 4) + r < p.ncoef_out) orow[r] = o4[r];
+                    }
                 }
             } else if (FEAT == FEAT_DCTC || IS_LP) {
                 cells_reduce<NC>(c);
