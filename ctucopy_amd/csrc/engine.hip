@@ -158,6 +158,7 @@ struct ctu_plan {
     DevBuf<int> tile_utt;            // utterance of every tile (SS)
     DevBuf<float> ss_seed, ss_last;  // SS: noise seeds per utterance [n_utt][K] and the vectors the utterances leave behind
     DevBuf<unsigned char> ss_dirty;  // SS: utterances a pass of the seed iteration recomputes
+    DevBuf<unsigned char> ss_vbits;  // SS: the detector's decision of every frame (first pass), reused by the later passes
     DevBuf<float2> xri;         // VAD scratch
     DevBuf<float> pnr;
     DevBuf<double> vad_ci;
@@ -330,6 +331,9 @@ bool lp_md_eligible(const ctu::Design &d) {
 bool md_eligible(const ctu::Design &d) { return (CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d))) || lp_md_eligible(d); }
 // hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 25 ms frames at 8 or 16 kHz, the
 // presets' 12 cepstral coefficients for the detector, the plain chain into cepstra or band energies
+#ifndef CTU_SS_CACHE
+#define CTU_SS_CACHE 1  // 0: every pass of the seed iteration runs the detector again (A/B)
+#endif
 int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode == "fwss" ? 2 : o.nr_mode == "2fwss" ? 3 : 0; }
 bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
@@ -1197,6 +1201,7 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
             pl->ss_seed.alloc((size_t)std::max(n_utt, 1) * d.K);
             pl->ss_last.alloc((size_t)std::max(n_utt, 1) * d.K);
             pl->ss_dirty.alloc((size_t)std::max(n_utt, 1));
+            pl->ss_vbits.alloc((size_t)std::max<int64_t>(ro, 1));
         }
         if (e->do_vad) {
             pl->d_row_off.upload(pl->row_off);
@@ -1463,7 +1468,10 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             // whose seed changed since the pass before (all of them in the first one).
             std::vector<unsigned char> dirty(std::max(pl->n_utt, 1), 1);
             kp.ss_dirty = pl->ss_dirty.p;
+            kp.ss_vbits = pl->ss_vbits.p;
             for (int iter = 0;; iter++) {
+                // the detector never sees a subtracted spectrum (nr.cc:278-295): its decisions are those of the first pass
+                kp.ss_cached = iter > 0 ? CTU_SS_CACHE : 0;
                 HIP_TRY(hipMemcpyAsync(pl->ss_seed.p, seed.data(), nk * sizeof(float), hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemcpyAsync(pl->ss_dirty.p, dirty.data(), dirty.size(), hipMemcpyHostToDevice, s));
                 launch();

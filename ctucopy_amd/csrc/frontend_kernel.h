@@ -618,6 +618,13 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                         snrav[j] = 0.f;
                     }
                 }
+                unsigned vbits = 0;
+                if (p.ss_cached) {
+                    // The detector sees the spectra as they come from the transform (step 1 below), never the subtracted ones: its
+                    // decisions do not depend on the noise seed.  The first pass of the seed iteration (engine.hip) stored them;
+                    // later passes subtract with the new seed on the spectra the step already holds.
+                    for (int f = 0; f < nv; f++) vbits |= (unsigned)(p.ss_vbits[rbase + slot0 + f] & 1) << f;
+                } else {
                 // (1) what the detector sees: X^a (X itself in 2fwss) with the original phase (nr.cc:278-295)
                 if (!two && p.nr_a != 1.0f) {
                     for (int f = 0; f < nv; f++) {
@@ -630,7 +637,6 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 double mine_ab[2];
                 rebuild_cepstra(std::integral_constant<int, SS_NC>{}, std::true_type{}, mine_ab);
                 // (2) the detector's recurrences over the step's frames, in order (src/vdet/CepstralDet.h:140-194)
-                unsigned vbits = 0;
                 for (int s_ = 0; s_ < nv; s_++) {
                     // frame slot s_: group s_ / 2, frame s_ % 2 of it (256-point mode); group s_ % 4 of half s_ / 4 (512-point mode)
                     const int src = ((16 * (MODE == 1 ? (s_ >> 1) : (s_ & 3)) + (lane & 15)) << 2);
@@ -640,8 +646,10 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     const double cil = lane < SS_NC ? got : 0.0;
                     vbits |= (unsigned)cepdet_frame(sdet, cil, lane, SS_NC, p.ss_init, p.nr_p_d, p.ss_q) << s_;
                 }
+                if (lane < nv) p.ss_vbits[rbase + slot0 + lane] = (unsigned char)((vbits >> lane) & 1u);
                 // (3) the spectra again, then the subtraction proper, frames in order, lane = bin
                 phase1(3);
+                }
                 const float pp = p.nr_p, qq = 1.0f - p.nr_p;
                 for (int f = 0; f < nv; f++) {
                     const int t = rec.t0 + slot0 + f;

@@ -90,6 +90,8 @@ struct KParams {
     float *ss_last;
     const int *tile_utt;
     const unsigned char *ss_dirty;  // [n_utt] or null: utterances to (re)compute in this pass of the seed iteration
+    unsigned char *ss_vbits;        // [total_frames]: the detector's decision of every frame, written by the first pass
+    int ss_cached;                  // later passes: take the decisions from ss_vbits (they do not depend on the noise seed)
     float *ybuf;      // SY instantiations: time-domain frames [total_frames][window] ahead of the overlap-add
     float syn_scale;  // SY: 1 / wfft (sigOUT's amplitude factor, src/io/out.cc:416-422)
     float *vad_cf;    // VF instantiations: Burg cepstra of every frame [total_frames][VFC_STRIDE] for vad_lanes_kernel
