@@ -145,3 +145,23 @@ def test_random_configurations_design_the_same_tables_or_fail_alike():
         assert np.array_equal(config_table(cfg, "fb_first"), first) and np.array_equal(config_table(cfg, "fb_last"), last), cfg
         ok += 1
     assert ok >= 30
+
+
+def test_arena_layout_rule():
+    """ctu_arena_layout (no engine, no device): utterance starts are multiples of pcm_align behind 8 samples of padding, regions do not
+    overlap, 512 samples of padding close the arena - what ctu_plan_create reports (the GPU tests compare the two on real plans)."""
+    L = ceng.load_library()
+    i64 = ctypes.c_int64
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 17, 400):
+        ns = rng.integers(0, 50000, size=n).astype(np.int64)
+        if n > 2:
+            ns[1] = 0
+        off = np.full(n + 1, -1, dtype=np.int64)
+        total = L.ctu_arena_layout(ns.ctypes.data_as(ctypes.POINTER(i64)), n, off.ctypes.data_as(ctypes.POINTER(i64)))
+        assert off[0] == 8 and total == off[n] + 512
+        assert np.all(off % 8 == 0) and np.all(off[1:] - off[:-1] >= ns) and np.all(off[1:] - off[:-1] < ns + 8)
+        assert L.ctu_arena_layout(ns.ctypes.data_as(ctypes.POINTER(i64)), n, None) == total  # offsets optional
+    bad = np.array([5, -1], dtype=np.int64)
+    assert L.ctu_arena_layout(bad.ctypes.data_as(ctypes.POINTER(i64)), 2, None) < 0
+    assert L.ctu_arena_layout(None, 3, None) < 0
