@@ -79,7 +79,7 @@ def test_kernel_names_key_the_profiles(Engine):
     from tests.util import C4
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert Engine(C2).kernel_name() == json.load(open(os.path.join(root, "profiles", "traffic.json")))["kernel"]
-    assert Engine(C3).kernel_name() == "frontend_kernel<13, LP, MODE 0, inld>"
+    assert Engine(C3).kernel_name() == "frontend_kernel<13, LP, MODE 0, inld, MD>"
     assert Engine(C4).kernel_name() == "frontend_kernel<13, DCTC, MODE 1, exten, MD, VF>"
     assert Engine(C2 + ["-w", "40"]).kernel_name() == "wave1k_kernel"
     assert Engine(C2 + ["-w", "80"]).kernel_name() == "bigfft_kernel<8>"
