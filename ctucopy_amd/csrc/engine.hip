@@ -1414,7 +1414,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             const int g = std::max(1, std::min(pl->n_tiles, e->n_cu * per_cu));
             if (e->wave1k) {
                 // 1024 points: one wave per frame, the transform in registers (wave1k_kernel.h); tiles are dealt to waves
-                const size_t wshm = ((size_t)W1K_WAVES * W1K_WAVE_FLOATS + 1024 + 2048 + (size_t)((e->big_fb_total + 3) & ~3) + 2) * 4 +
+                const size_t wshm = ((size_t)W1K_WAVES * W1K_WAVE_FLOATS + 1024 + W1K_TW_FLOATS + (size_t)((e->big_fb_total + 3) & ~3) + 2) * 4 +
                                     (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
                                     (size_t)(((e->feat == FEAT_DCTC ? e->ncoef_out * d.B : 0) + 3) & ~3) * 4 + (size_t)((3 * d.B + 3) & ~3) * 4 + (size_t)(256 + 2 * d.B) * 4 + 64;
                 if (wshm > 160 * 1024) throw std::runtime_error("filter bank too wide for the LDS tables of the 1024-point kernel");

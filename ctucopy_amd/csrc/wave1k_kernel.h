@@ -54,6 +54,7 @@ constexpr int W1K_TS = 72;                       // dwords between the rows of t
 constexpr int W1K_PLANE = 8 * W1K_TS;            // the plane: re and im of a transpose go through it one after the other; the power
                                                  // spectrum P[513 (+3)] takes its place once the transform is done
 constexpr int W1K_WAVE_FLOATS = W1K_PLANE + 64 + 64 + 64;  // plane / P | Y[64] | Ylog[64] | partial band sums [64]
+constexpr int W1K_TW_FLOATS = 2 * (512 + 64 + 512);        // W1024^m for m < 512 | t1[8][8] | t2[8][64], float2 each
 #ifndef CTU_W1K_WAVES
 #define CTU_W1K_WAVES 4  // measured (profiles/r03_ab_wave1k_occupancy.txt, 1.78 M frames): 4 waves x 5 workgroups per CU (96 VGPRs) 2.86 ms,
 #define CTU_W1K_LB 5     // 8 x 3 (80 VGPRs, 35 spilled) 3.09 ms, 4 x 4 (120 VGPRs, none spilled) 3.05 ms; round 3's first version (163 VGPRs, 3 per SIMD) 4.10 ms
@@ -74,8 +75,12 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
     float *Y = wbase + W1K_PLANE, *Ylog = Y + 64, *part_s = Ylog + 64;
     float *tab = smem + W1K_WAVES * W1K_WAVE_FLOATS;
     float2 *lwin2 = reinterpret_cast<float2 *>(tab);           // [512] (w[2n], w[2n+1]), zero beyond the window
-    float2 *ltw = reinterpret_cast<float2 *>(tab + 1024);      // [1024] W1024^m = e^{-2 pi i m / 1024}
-    float *lfb = tab + 1024 + 2048;
+    float2 *ltw = reinterpret_cast<float2 *>(tab + 1024);      // [512] W1024^m = e^{-2 pi i m / 1024}, m < 512 (the untangle's W1024^k)
+    // the stages' twiddles laid out as they are read: t1[r][n1] (eight distinct values per read, eight neighbouring entries) and
+    // t2[r][lane] - out of the shared W1024 table they sat 128 n1 r bytes apart, all on one bank (SQ_LDS_BANK_CONFLICT: 247 of the
+    // kernel's 651 LDS cycles per frame, profiles/r03_pmc_configs.txt)
+    float2 *lt1 = ltw + 512, *lt2 = lt1 + 64;
+    float *lfb = tab + 1024 + W1K_TW_FLOATS;
     double *lcoef_d = reinterpret_cast<double *>(lfb + ((p.fb_total + 3) & ~3) + (((p.fb_total + 3) & ~3) & 1));
     const int ncd = (p.feat == FEAT_LP) ? (p.lporder + 1) * p.B : 0, ncf = (p.feat == FEAT_DCTC) ? p.ncoef_out * p.B : 0;
     float *lcoef = reinterpret_cast<float *>(lcoef_d + ncd);
@@ -83,9 +88,17 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
     int *lseg = lrange + ((3 * p.B + 3) & ~3);                        // [64][4] {band, first bin, bins, weight offset} | [B][2] {first lane, lanes}
     constexpr int NT_ = 64 * W1K_WAVES;
     for (int i = tid; i < 1024; i += NT_) tab[i] = i < p.window ? p.win[i] : 0.f;
-    for (int i = tid; i < 1024; i += NT_) {  // p.tw holds m < 512: the other half is its negative
-        const float2 t = p.tw[i & 511];
-        ltw[i] = i & 512 ? make_float2(-t.x, -t.y) : t;
+    auto w1024 = [&](int m) {  // p.tw holds m < 512: the other half is its negative
+        const float2 t = p.tw[m & 511];
+        return m & 512 ? make_float2(-t.x, -t.y) : t;
+    };
+    for (int i = tid; i < 512; i += NT_) ltw[i] = p.tw[i];
+    // after step 1, lane (n0 = d0, n1 = d1), register k2 = r: W64^(n1 k2) = W1024^(16 n1 r); after step 2, lane (n0 = d0, k2 = d1),
+    // register k1 = r: W512^(n0 (k2 + 8 k1)) = W1024^(2 n0 k2 + 16 n0 r)
+    for (int i = tid; i < 64; i += NT_) lt1[i] = w1024((16 * (i & 7) * (i >> 3)) & 1023);
+    for (int i = tid; i < 512; i += NT_) {
+        const int l_ = i & 63, r_ = i >> 6;
+        lt2[i] = w1024((2 * (l_ & 7) * (l_ >> 3) + 16 * (l_ & 7) * r_) & 1023);
     }
     for (int i = tid; i < p.fb_total; i += NT_) lfb[i] = p.fbw[i];
     for (int i = tid; i < ncd; i += NT_) lcoef_d[i] = p.coef_d[i];
@@ -95,9 +108,6 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
     __syncthreads();  // the only workgroup barrier: tables are in place
 
     const int d0 = lane & 7, d1 = lane >> 3;  // low / high digit of the lane number
-    // twiddle indices into W1024 (W512^j = W1024^(2j)):  after step 1, lane (n0 = d0, n1 = d1), register k2 = r: W64^(n1 k2) = W1024^(16 n1 r);
-    // after step 2, lane (n0 = d0, k2 = d1), register k1 = r: W512^(n0 (k2 + 8 k1)) = W1024^(2 n0 k2 + 16 n0 r)
-    const int tw1_step = 16 * d1, tw2_base = 2 * d0 * d1, tw2_step = 16 * d0;
     const int mirror = ((64 - lane) & 63) << 2;
     // output slots of the DCT rows 4 (lane / 16) + r this lane stores (-1: not written): read once, not per frame
     int slot_of_row[4];
@@ -168,11 +178,11 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
             };
             dft8(v);
 #pragma unroll
-            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], ltw[(tw1_step * r) & 1023]);
+            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], lt1[8 * r + d1]);
             exchange(d0 + W1K_TS * d1, 8);      // element (n0, n1, k2 = r) -> row n1, column n0 + 8 k2; then lane = n0 + 8 k2, register n1
             dft8(v);
 #pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = cmul(v[r], ltw[(tw2_base + tw2_step * r) & 1023]);
+            for (int r = 0; r < 8; r++) v[r] = cmul(v[r], lt2[64 * r + lane]);
             exchange(d1 + W1K_TS * d0, 8);      // element (n0, k1 = r, k2) -> row n0, column k2 + 8 k1; then lane = k2 + 8 k1, register n0
             dft8(v);  // v[r] = Z[lane + 64 r]
             // ---- untangle the packed transform, |.|^2 (src/io/in.cc:388-394): bin k = lane + 64 r with Z[512 - k] from lane
