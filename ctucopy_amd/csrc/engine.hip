@@ -110,6 +110,7 @@ struct ctu_engine {
     DevBuf<double> big_coef_d;
     int lift_off = 0, tab_floats = 0, ck_off = 0, cf_off = 0, cfd_off = 0, am_off = 0, NS = 0, CW = 4, ncoef_out = 0;
     bool md = false;        // DCT tail on the matrix cores (frontend_kernel<..., MD>): tables are laid out for its lane map
+    bool half_window = false;  // the headline instantiation (DUAL): the window table is scaled by 1/2, which is the 1/4 of its power spectrum
     bool vf = false;        // Burg-cepstral VAD criterion fused into the front end (frontend_kernel<..., VF>)
     bool sy = false;        // speech-enhancement output with the inverse transform inside the front end (frontend_kernel<..., SY>)
     int ss = 0;             // hwss / fwss / 2fwss (1 / 2 / 3) on frontend_kernel<..., SS>
@@ -798,6 +799,16 @@ void build_tables(ctu_engine *e) {
         case ctu::FeaKind::None: e->feat = FEAT_BANDS; break;  // not reached: the signal path returns above
     }
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
+    // The headline instantiation (frontend_kernel.h, DUAL) takes its window scaled by 1/2: the packed transform's untangle owes the
+    // power spectrum a factor 1/4, and a power of two on the window goes through every rounding of the chain unchanged - the rows are
+    // bit for bit those of 0.25f * (re^2 + im^2), two multiplications per bin pair cheaper.  launch_vx checks that the instantiation
+    // it launches is the one the table was scaled for.
+    e->half_window = CTU_DUAL && e->md && e->feat == FEAT_DCTC && !e->vf && !e->ss && !e->sy && e->mode == 0 && e->nz == 13 && d.o.nr_mode != "exten";
+    if (e->half_window) {
+        for (int l = 0; l < 16; l++)
+            for (int j = 0; j < 32; j++) lc[(size_t)l * LANEC + LC_WIN + j] *= 0.5f;
+        e->lanec.upload(lc);
+    }
 }
 
 // One front-end launch.  The 160 KiB dynamic-LDS attribute is set once per engine (= per device) and instantiation.
@@ -838,6 +849,11 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const int feat = e->feat;
     const bool base = !vx && kp.e_mode == 0 && kp.fb_power && kp.remove_dc && !kp.remove_dc1 && !kp.dbg && !kp.skip_phase2 && !kp.nr_after_fb;
     const bool narrow = kp.CW == 16;
+    {   // the window table of this engine is scaled for exactly one instantiation (ctu_engine::half_window)
+        constexpr bool dual_shape = CTU_DUAL && MODE == 0 && NZ < 16;
+        const bool dual = dual_shape && !(e->sy && kp.skip_phase2) && !kp.remove_dc1 && !e->ss && !e->vf && e->md && feat == FEAT_DCTC && !kp.nr_exten;
+        if (dual != e->half_window) throw std::runtime_error("internal: window table scaled for another instantiation");
+    }
     if (e->sy && kp.skip_phase2) {
         if (kp.remove_dc1) {
             if constexpr (NZ == 16) launch_fe(e, &frontend_kernel<16, FEAT_BANDS, MODE, false, 16, GEN_DC1, 0, false, false, false, true>, grid, s, kp);

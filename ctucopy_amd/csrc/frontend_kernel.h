@@ -278,15 +278,17 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                         const float tr = wr * di + wi * dr;
                         const float ti = wi * di - wr * dr;
                         const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
-                        prow[k] = 0.25f * (ur * ur + ui * ui);
-                        prow[256 - k] = 0.25f * (vr * vr + vi * vi);
+                        // the untangle's 1/4 is in the window (the engine scales this instantiation's table by 1/2: ctu_engine::half_window)
+                        prow[k] = ur * ur + ui * ui;
+                        prow[256 - k] = vr * vr + vi * vi;
                     };
                     untangle(v0, pr0);
                     untangle(v1, pr1);
                 }
-                if (l16 == 0) {  // bin 128 is its own mirror; bin 0 floor (src/io/in.cc:390)
-                    pr0[128] = v0[8].x * v0[8].x + v0[8].y * v0[8].y;
-                    pr1[128] = v1[8].x * v1[8].x + v1[8].y * v1[8].y;
+                if (l16 == 0) {  // bin 128 is its own mirror (no 1/4 there: the halved window is undone); bin 0 floor (src/io/in.cc:390)
+                    const float a0 = 2.f * v0[8].x, b0 = 2.f * v0[8].y, a1 = 2.f * v1[8].x, b1 = 2.f * v1[8].y;
+                    pr0[128] = a0 * a0 + b0 * b0;
+                    pr1[128] = a1 * a1 + b1 * b1;
                     pr0[0] = pr1[0] = 1e-10f;
                 }
             }
