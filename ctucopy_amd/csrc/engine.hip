@@ -1634,7 +1634,10 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             HIP_TRY(hipGetLastError());
         }
         if (e->do_vad && e->vf && pl->n_live > 0) {
-            // the fused path left the Burg cepstra of every frame behind: the detector's recurrences, sixteen utterances per wave
+            // the fused path left the lattice's output of every frame behind: the coefficient recursion and a -> c one frame per lane,
+            // then the detector's recurrences, sixteen utterances per wave
+            if (CTU_VF_A2C)
+                hipLaunchKernelGGL((vad_a2c_kernel<VF_NC>), dim3((unsigned)((pl->total_frames + 255) / 256)), dim3(256), 0, s, pl->vad_cf.p, (int64_t)pl->total_frames);
             hipLaunchKernelGGL((vad_lanes_kernel<VF_NC>), dim3((pl->n_live + 15) / 16), dim3(64), 0, s, pl->vad_cf.p, pl->vf_order.p, pl->n_live,
                                pl->d_row_off.p, d_vad, e->vp);
             HIP_TRY(hipGetLastError());

@@ -520,6 +520,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         auto rebuild_cepstra = [&](auto NCO, auto HANN, auto (&out)[2]) {
             constexpr int nco = decltype(NCO)::value;
             typedef std::remove_reference_t<decltype(out[0])> real_t;  // float, or double for the *ss detector (vad_fused.h)
+            // the VAD module's criterion (no Hann window, float): the lattice only - {alpha, k_m} go to the scratch rows and
+            // vad_a2c_kernel finishes the cepstra one frame per lane; the *ss detector needs its cepstra here and now
+            constexpr bool rc_only = CTU_VF_A2C && !decltype(HANN)::value && sizeof(real_t) == 4;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if constexpr (MODE == 1) {
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF_JW, real_t>(x, l16, VF_LW, VF_JW, (real_t)p.inv_window_d, cc);
+                vf_burg_cepstrum<nco, VF_JW, real_t, VF_SPL, rc_only>(x, l16, VF_LW, VF_JW, (real_t)p.inv_window_d, cc);
                 real_t mine = cc[0];
 #pragma unroll
                 for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF0_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL>(x, l16, VF0_LW, VF0_JW, (real_t)p.inv_window_d, cc);
+                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL, rc_only>(x, l16, VF0_LW, VF0_JW, (real_t)p.inv_window_d, cc);
                 real_t mine = cc[0];
 #pragma unroll
                 for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;

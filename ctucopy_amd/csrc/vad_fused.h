@@ -177,7 +177,45 @@ __device__ __forceinline__ void vf_inverse_fft(float2 (&vn)[16], const float4 *l
 #ifndef CTU_BURG_DREC
 #define CTU_BURG_DREC 0  // 1: the denominator of order m+1 from that of order m, D' = (1 - k^2) D - f[m]^2 - b[N-1]^2, instead of the sum
 #endif
-template <int NC, int JW, class T, int SPL = VF_SPL>
+// The tail of the Burg estimator behind the lattice: from the reflection coefficients (FROM_RC: the polynomial is rebuilt first,
+// a_i <- a_i + k a_{m-i}, Burg.h:88-93) to the LPC cepstrum c_0 = ln alpha, c_m = -a_m - (1/m) sum_{k<m} (m-k) c_{m-k} a_k
+// (Burg.h:143-151).  One definition for the front end (all lanes of a frame) and for vad_a2c_kernel (one frame per lane), so that
+// both round alike.
+template <int NC, class T, bool FROM_RC>
+__device__ __forceinline__ void vf_lattice_to_cepstrum(T alpha, T (&a)[NC], T (&cc)[NC]) {
+    if constexpr (FROM_RC) {  // a[m] holds the reflection coefficient of order m on entry
+        T rcs[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            rcs[i] = a[i];
+            a[i] = i == 0 ? (T)1 : (T)0;
+        }
+#pragma unroll
+        for (int ik = 1; ik < NC; ik++) {
+            const T rc = rcs[ik];
+            T an[NC];
+#pragma unroll
+            for (int i = 1; i < ik; i++) an[i] = a[i] + rc * a[ik - i];
+#pragma unroll
+            for (int i = 1; i < ik; i++) a[i] = an[i];
+            a[ik] = rc;
+        }
+    }
+    if constexpr (sizeof(T) == 8) cc[0] = log(alpha);
+    else cc[0] = __builtin_amdgcn_logf(alpha) * 0.69314718056f;
+#pragma unroll
+    for (int m = 1; m < NC; m++) {
+        T sum = 0;
+#pragma unroll
+        for (int k = 1; k < m; k++) sum += (T)(m - k) * cc[m - k] * a[k];
+        cc[m] = -a[m] - sum * ((T)1 / (T)m);
+    }
+}
+
+// RC_ONLY: stop at the lattice - cc[0] = the residual energy alpha, cc[m] = reflection coefficient of order m.  The coefficient
+// recursion (Burg.h:88-93) and a -> c (Burg.h:143-151) are one short sequential recursion per FRAME which all sixteen lanes of a
+// frame would repeat: vad_a2c_kernel (vad_kernels.h) finishes them one frame per lane, with these very expressions.
+template <int NC, int JW, class T, int SPL = VF_SPL, bool RC_ONLY = false>
 __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
     constexpr int VF_SPL = SPL;  // samples per lane (13: 256-point mode, 25: 512-point mode); shadows the global of the same name
     T ef[VF_SPL], eb[VF_SPL];
@@ -255,23 +293,19 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
                 den_next = ((T)1 - rc * rc) * den - row_sum(fe * fe + be * be);
             }
             clear_last();
-            T an[NC];
+            if constexpr (RC_ONLY) cc[ik] = rc;
+            else {
+                T an[NC];
 #pragma unroll
-            for (int i = 1; i < ik; i++) an[i] = a[i] + rc * a[ik - i];
+                for (int i = 1; i < ik; i++) an[i] = a[i] + rc * a[ik - i];
 #pragma unroll
-            for (int i = 1; i < ik; i++) a[i] = an[i];
-            a[ik] = rc;
+                for (int i = 1; i < ik; i++) a[i] = an[i];
+                a[ik] = rc;
+            }
         }
     }
-    if constexpr (sizeof(T) == 8) cc[0] = log(alpha);
-    else cc[0] = __builtin_amdgcn_logf(alpha) * 0.69314718056f;
-#pragma unroll
-    for (int m = 1; m < NC; m++) {
-        T sum = 0;
-#pragma unroll
-        for (int k = 1; k < m; k++) sum += (T)(m - k) * cc[m - k] * a[k];
-        cc[m] = -a[m] - sum * ((T)1 / (T)m);
-    }
+    if constexpr (RC_ONLY) cc[0] = alpha;
+    else vf_lattice_to_cepstrum<NC, T, false>(alpha, a, cc);
 }
 
 // X^a and X^(1/a) of the *ss modes (src/nr/nr.cc:229-234, 252-257): exact for a = 1, 2, pow otherwise.
@@ -314,6 +348,36 @@ __device__ __forceinline__ int cepdet_frame(CepDetRun &d, double cil, int lane, 
     }
     ++d.nseg;
     return result;
+}
+
+// The coefficient recursion and a -> c of the fused Burg-cepstral criterion, one frame per lane (see RC_ONLY above): a row of the
+// scratch holds {alpha, k_1 .. k_{NC-1}} when the front end leaves it and the NC cepstra afterwards, which is what vad_lanes_kernel
+// reads.  The front end's sixteen lanes per frame spent 65 vector instructions per frame repeating this; here it is 4.
+#ifndef CTU_VF_A2C
+#define CTU_VF_A2C 1  // 0: the tail stays inside the front end (A/B)
+#endif
+template <int NC>
+__global__ __launch_bounds__(256) void vad_a2c_kernel(float *__restrict__ cf, int64_t total_frames) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total_frames) return;
+    float4 *row = reinterpret_cast<float4 *>(cf + t * VFC_STRIDE);
+    float v[VFC_STRIDE];
+#pragma unroll
+    for (int q = 0; q < VFC_STRIDE / 4; q++) {
+        const float4 x = row[q];
+        v[4 * q] = x.x;
+        v[4 * q + 1] = x.y;
+        v[4 * q + 2] = x.z;
+        v[4 * q + 3] = x.w;
+    }
+    float a[NC], cc[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) a[i] = v[i];
+    vf_lattice_to_cepstrum<NC, float, true>(v[0], a, cc);
+#pragma unroll
+    for (int i = 0; i < NC; i++) v[i] = cc[i];
+#pragma unroll
+    for (int q = 0; q < VFC_STRIDE / 4; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
 }  // namespace
