@@ -115,6 +115,10 @@ struct ctu_engine {
     bool sy = false;        // speech-enhancement output with the inverse transform inside the front end (frontend_kernel<..., SY>)
     int ss = 0;             // hwss / fwss / 2fwss (1 / 2 / 3) on frontend_kernel<..., SS>
     std::vector<float> ss_stale;  // the spectrum vector the last file of the previous run left behind (zeros at first)
+    // -vad file=<f>: ONE byte stream for all files of the process, a byte per frame, never rewound (nr.cc:205-209, 273, 297-302)
+    bool ss_file = false;
+    std::vector<unsigned char> vad_stream;
+    int64_t vad_pos = 0;
     int han_off = 0;
     bool per_wave = false;  // chains per wave (state along an utterance lives in a wave's registers)
     size_t lds_bytes = 0;
@@ -217,8 +221,7 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (o.do_vad() && !(o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea")) return "-remove_dc1 together with a VAD criterion on the spectrum";
     }
     if (o.nr_mode != "none" && o.nr_mode != "exten") {
-        if (o.vadmode == "file") return "-vad file=...: one byte stream for all files, every byte but NUL counts as speech (src/nr/nr.cc:297-301)";
-        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg, 12 cepstral coefficients, plain chain)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., plain chain)";
     }
     if (o.nr_when_afterFB) {
         if (d.post_order > 0 || d.cms || o.stat_cmvn || o.apply_cmvn || o.do_vad() || d.signal_out) return "-nr_when afterFB together with post-processing, VAD or signal output";
@@ -339,8 +342,9 @@ int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode 
 bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
-    return CTU_MD && ss_mode_of(o) && o.vadmode == "burg" && !o.nr_when_afterFB && fused_frame_shape(d) &&
-           o.fea_ncepcoefs == SS_NC && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !o.do_vad() && !d.signal_out &&
+    // -vad file=<f> (nr.cc:205-209, 297-302): the decisions come from a byte stream instead of the detector; same kernel, same frame shapes
+    const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
+    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !o.do_vad() && !d.signal_out &&
            !o.rasta && d.post_order == 0 && !d.cms && !o.stat_cmvn && !o.apply_cmvn;
 }
 
@@ -774,6 +778,7 @@ void build_tables(ctu_engine *e) {
     e->md = t.md;
     e->vf = vf_eligible(d);
     e->ss = ss_eligible(d) ? ss_mode_of(d.o) : 0;
+    e->ss_file = e->ss && d.o.vadmode == "file";
     e->han_off = t.han_off;
     e->tab_floats = t.tab_floats;
     e->NS = t.NS;
@@ -1019,6 +1024,17 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
     if (!why.empty()) {
         g_create_error = "ENGINE: configuration not on the accelerated path: " + why;
         return CTU_ERR_UNSUPPORTED;
+    }
+    if (ss_mode_of(e->design->o) && e->design->o.vadmode == "file") {  // hwssNR::hwssNR opens it (nr.cc:205-209); ctu_engine_set_vad_stream replaces it
+        FILE *f = std::fopen(e->design->o.filevad.c_str(), "rb");
+        if (!f) {
+            g_create_error = "NR: Unable to open VAD file!\n";
+            return CTU_ERR_OPTS;
+        }
+        unsigned char tmp[1 << 16];
+        size_t got;
+        while ((got = std::fread(tmp, 1, sizeof tmp, f)) > 0) e->vad_stream.insert(e->vad_stream.end(), tmp, tmp + got);
+        std::fclose(f);
     }
     try {
         int ndev = 0;
@@ -1485,9 +1501,26 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             std::vector<unsigned char> dirty(std::max(pl->n_utt, 1), 1);
             kp.ss_dirty = pl->ss_dirty.p;
             kp.ss_vbits = pl->ss_vbits.p;
+            if (e->ss_file) {
+                // -vad file=<f>: `char vad = fgetc(fvad); if (vad != EOF) return bool(vad); else throw` (nr.cc:297-302), one byte per frame in
+                // list order, the stream running on from file to file and from run to run.  Every byte but NUL is speech; a byte 0xFF
+                // compares equal to EOF in the reference's (signed) char and ends the run like the end of the file does.
+                const int64_t nf = pl->total_frames;
+                std::vector<unsigned char> vb((size_t)std::max<int64_t>(nf, 1), 0);
+                for (int64_t i = 0; i < nf; i++) {
+                    if (e->vad_pos + i >= (int64_t)e->vad_stream.size() || e->vad_stream[(size_t)(e->vad_pos + i)] == 0xFF) {
+                        set_error(e, "NR: Unexpected end of VAD file!");
+                        return CTU_ERR_INPUT;
+                    }
+                    vb[(size_t)i] = e->vad_stream[(size_t)(e->vad_pos + i)] != 0;
+                }
+                HIP_TRY(hipMemcpyAsync(pl->ss_vbits.p, vb.data(), (size_t)nf, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipStreamSynchronize(s));  // vb leaves scope
+                e->vad_pos += nf;
+            }
             for (int iter = 0;; iter++) {
                 // the detector never sees a subtracted spectrum (nr.cc:278-295): its decisions are those of the first pass
-                kp.ss_cached = iter > 0 ? CTU_SS_CACHE : 0;
+                kp.ss_cached = e->ss_file ? 1 : (iter > 0 ? CTU_SS_CACHE : 0);
                 HIP_TRY(hipMemcpyAsync(pl->ss_seed.p, seed.data(), nk * sizeof(float), hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemcpyAsync(pl->ss_dirty.p, dirty.data(), dirty.size(), hipMemcpyHostToDevice, s));
                 launch();
@@ -2038,6 +2071,18 @@ int ctu_decode_g711(ctu_engine *e, const uint8_t *d_codes, int64_t n, int alaw, 
 int ctu_engine_reset_chain(ctu_engine *e) {
     if (!e) return CTU_ERR_INPUT;
     e->ss_stale.clear();
+    e->vad_pos = 0;
+    return CTU_OK;
+}
+
+int ctu_engine_set_vad_stream(ctu_engine *e, const unsigned char *bytes, int64_t n) {
+    if (!e || n < 0 || (n && !bytes)) return CTU_ERR_INPUT;
+    if (!e->ss_file) {
+        set_error(e, "ENGINE: this configuration does not take its VAD decisions from a stream (-nr_mode hwss|fwss|2fwss -vad file=...)");
+        return CTU_ERR_INPUT;
+    }
+    e->vad_stream.assign(bytes, bytes + n);
+    e->vad_pos = 0;
     return CTU_OK;
 }
 

@@ -32,7 +32,7 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_arena_layout", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_engine_set_vad_stream", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
 
@@ -77,6 +77,7 @@ def load_library():
     L.ctu_engine_run.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_run_host.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_reset_chain.argtypes = [vp]
+    L.ctu_engine_set_vad_stream.argtypes = [vp, ctypes.c_char_p, i64]
     L.ctu_decode_g711.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
     L.ctu_host_alloc.restype = vp
     L.ctu_host_alloc.argtypes = [ctypes.c_size_t]
@@ -292,6 +293,11 @@ class Engine:
         s = stream if stream is not None else torch.cuda.current_stream(codes.device)
         self._check(load_library().ctu_decode_g711(self._h, codes.data_ptr(), codes.numel(), 1 if alaw else 0, out.data_ptr(), s.cuda_stream))
         return out
+
+    def set_vad_stream(self, data):
+        """-vad file=...: replaces the byte stream the hwss / fwss / 2fwss decisions are read from (one byte per frame) and rewinds it."""
+        data = bytes(data)
+        self._check(load_library().ctu_engine_set_vad_stream(self._h, data, len(data)))
 
     def reset_chain(self):
         """hwss / fwss / 2fwss: forget the spectrum vector the previous run left behind (see include/ctu_engine.h)."""

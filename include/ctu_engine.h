@@ -128,6 +128,11 @@ int ctu_decode_g711(ctu_engine *, const uint8_t *d_codes, int64_t n, int alaw, i
  * order as that chain (synchronously: the seeds are iterated to their fixed point) and the engine keeps the last vector
  * for the next run, as the reference keeps it for the life of the process; this call forgets it (a new process). */
 int ctu_engine_reset_chain(ctu_engine *);
+/* -vad file=<f> with those modes (hwssNR::vad_get_frame, src/nr/nr.cc:297-302): the decisions come from ONE byte stream for all files
+ * of the process, one byte per frame in list order - every byte but NUL is speech, a byte 0xFF ends the run like the end of the
+ * stream does ("NR: Unexpected end of VAD file!").  ctu_engine_create reads <f> (src/nr/nr.cc:205-209); this call replaces the
+ * stream and rewinds it, ctu_engine_reset_chain rewinds it. */
+int ctu_engine_set_vad_stream(ctu_engine *, const unsigned char *bytes, int64_t n);
 
 /* Timing of the last ctu_engine_run on this engine, measured with HIP events on the run's stream
  * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */

@@ -91,6 +91,11 @@ struct ctuo {
      * as the previous file left it (src/nr/nr.cc:212-221,402-409; all zeros before the first file, base/types.h:35-38). */
     double *ss_stale;   /* K: _Xsabs after the last process_frame */
     int ss_mode;        /* 0 none, 1 hwss, 2 fwss, 3 2fwss */
+    /* -vad file=<f> (nr.cc:205-209,297-302): ONE byte stream for all files of the process, one byte per frame, opened by the
+     * constructor and never rewound ("no separation of files in VAD file (yes, it is dangerous, but...)", nr.cc:273) */
+    unsigned char *vad_stream;
+    long vad_len, vad_pos;
+    int vad_from_file;
 };
 
 static void set_err(ctuo_t *c, const char *msg) {
@@ -731,8 +736,21 @@ static int design_all(ctuo_t *c) {
     if (strcmp(o->nr_mode, "none") && strcmp(o->nr_mode, "exten") && !c->ss_mode) { set_err(c, "NR: Unknown noise reduction mode!"); return -1; }
     if (c->ss_mode) { /* src/nr/nr.cc:181-442 */
         if (!strcmp(o->vadmode, "none")) { set_err(c, "NR: Please specify Voice Activity Detector!"); return -1; } /* nr.cc:271 */
-        if (strcmp(o->vadmode, "burg")) { set_err(c, "oracle: -vad file=... reads one stream for all files and treats every byte but NUL as speech (src/nr/nr.cc:297-301); not restated"); return -1; }
-        if (o->nr_when_afterFB) { set_err(c, "NR: Cannot use Burg detector after filter bank!"); return -1; } /* nr.cc:194-195 */
+        if (!strcmp(o->vadmode, "file")) { /* hwssNR::hwssNR, nr.cc:205-209: fopen(filevad, "r") */
+            FILE *f = fopen(o->filevad, "rb");
+            if (!f) { set_err(c, "NR: Unable to open VAD file!\n"); return -1; }
+            long cap = 1 << 16, n = 0;
+            unsigned char *buf = malloc((size_t)cap);
+            size_t got;
+            while ((got = fread(buf + n, 1, (size_t)(cap - n), f)) > 0) {
+                n += (long)got;
+                if (n == cap) { cap *= 2; buf = realloc(buf, (size_t)cap); }
+            }
+            fclose(f);
+            c->vad_stream = buf; c->vad_len = n; c->vad_pos = 0; c->vad_from_file = 1;
+        } else if (strcmp(o->vadmode, "burg")) { set_err(c, "NR: Unknown VAD mode!"); return -1; } /* nr.cc:276 */
+        if (!c->vad_from_file && o->nr_when_afterFB) { set_err(c, "NR: Cannot use Burg detector after filter bank!"); return -1; } /* nr.cc:194-195 */
+        if (c->vad_from_file && o->nr_when_afterFB) { set_err(c, "oracle: hwss/fwss/2fwss after the filter bank are not restated"); return -1; }
         if (c->signal_out || o->rasta) { set_err(c, "oracle: hwss/fwss/2fwss are restated on the feature path only"); return -1; }
     }
     if (o->stat_cmvn || o->apply_cmvn) {
@@ -907,7 +925,7 @@ void ctuo_destroy(ctuo_t *c) {
     if (c->mat) { for (int i = 0; i < MAXB; i++) free(c->mat[i]); free(c->mat); }
     free(c->warp); free(c->hz); free(c->wdct); free(c->lift); free(c->WRe); free(c->trap_hamm);
     free(c->tw_re); free(c->tw_im); free(c->ut_re); free(c->ut_im);
-    free(c->last_power); free(c->last_fbank); free(c->ss_stale);
+    free(c->last_power); free(c->last_fbank); free(c->ss_stale); free(c->vad_stream);
     free(c);
 }
 
@@ -1563,10 +1581,20 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                         if (aexp == 2.0) for (int i = 0; i < K; i++) X[i] *= X[i];
                         else if (aexp != 1.0) for (int i = 0; i < K; i++) X[i] = pow(X[i], aexp);
                     }
-                    /* vad_get_frame, nr.cc:278-295: back to the time domain with the original phase, first `window` samples */
-                    for (int i = 0; i < K; i++) { ss_re[i] = X[i] * cos(Xph[i]); ss_im[i] = (i == 0 || i == K - 1) ? 0.0 : X[i] * sin(Xph[i]); }
-                    hc2r(ss_re, ss_im, wfft, ss_t, ss_w1, ss_w2);
-                    const int vad = ctuo_cepdet_process(ss_det, ss_t);
+                    int vad;
+                    if (c->vad_from_file) {
+                        /* nr.cc:297-302: `char vad = fgetc(fvad); if (vad != EOF) return bool(vad); else throw ...` - every byte but NUL
+                         * is speech (an ASCII '0' too), and a byte 0xFF compares equal to EOF in the (signed) char and ends the run */
+                        const int ch = c->vad_pos < c->vad_len ? (int)c->vad_stream[c->vad_pos++] : EOF;
+                        const char vc = (char)ch;
+                        if (vc == EOF) { set_err(c, "NR: Unexpected end of VAD file!"); fail = 1; break; }
+                        vad = vc != 0;
+                    } else {
+                        /* vad_get_frame, nr.cc:278-295: back to the time domain with the original phase, first `window` samples */
+                        for (int i = 0; i < K; i++) { ss_re[i] = X[i] * cos(Xph[i]); ss_im[i] = (i == 0 || i == K - 1) ? 0.0 : X[i] * sin(Xph[i]); }
+                        hc2r(ss_re, ss_im, wfft, ss_t, ss_w1, ss_w2);
+                        vad = ctuo_cepdet_process(ss_det, ss_t);
+                    }
                     if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) Navg[i] = p * Navg[i] + (1 - p) * X[i];
                     if (c->ss_mode == 3) {
                         for (int i = 0; i < K; i++) { X[i] -= Navg[i]; if (X[i] < 0.) X[i] = -X[i]; }

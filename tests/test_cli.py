@@ -443,3 +443,39 @@ def test_a_bad_file_stops_the_list_after_the_batches_in_front_of_it(tmp_path):
     np.zeros(100, dtype="<i2").tofile(tmp_path / "i" / "f025.raw")
     r = run("-fs 16000 -format_in raw -format_out htk -preset mfcc -S".split() + [lst, "--batch-mib", "1"])
     assert r.returncode == 255 and "Signal shorter than one frame" in r.stderr
+
+
+@pytest.mark.gpu
+def test_vad_decisions_from_a_file_through_the_cli(tmp_path):
+    """-nr_mode fwss -vad file=<f> (src/nr/nr.cc:205-209, 297-302): one byte per frame out of one stream for the whole list,
+    spread over several small batches by --batch-mib; a stream one byte short ends the run with the reference's text."""
+    from tests.util import C2, synth_utt
+    lens = [30000, 12000, 240, 20000, 9000, 16000, 31000]
+    lines, utts = [], []
+    for i, n in enumerate(lens):
+        f = tmp_path / f"u{i}.raw"
+        u = synth_utt(600 + i, n)
+        u.astype("<i2").tofile(f)
+        utts.append(u)
+        lines.append(f"{f} {tmp_path / f'u{i}.htk'}")
+    (tmp_path / "list").write_text("\n".join(lines) + "\n")
+    frames = [max((n - 240) // 160, 0) for n in lens]
+    stream = np.random.default_rng(4).integers(0, 2, sum(frames)).astype(np.uint8)
+    (tmp_path / "vad.bin").write_bytes(bytes(stream))
+    cfg = C2 + ["-nr_mode", "fwss", "-vad", f"file={tmp_path / 'vad.bin'}"]
+    r = run(cfg + ["-S", str(tmp_path / "list"), "--batch-mib", "1"])
+    assert r.returncode == 0, r.stderr
+    orc = Oracle(cfg)
+    for i, u in enumerate(utts):
+        ref = orc.process(u)
+        raw = (tmp_path / f"u{i}.htk").read_bytes()
+        n = struct.unpack("<I", raw[:4])[0]
+        assert n == ref.shape[0] == frames[i]
+        if n:
+            got = np.frombuffer(raw[12:], dtype="<f4").reshape(n, -1)
+            assert np.all(np.abs(got - ref) <= 1e-3 * np.maximum(np.abs(ref), 1.0)) and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() * 10
+    (tmp_path / "vad.bin").write_bytes(bytes(stream[:-1]))
+    r = run(cfg + ["-S", str(tmp_path / "list")])
+    assert r.returncode == 255 and "Unexpected end of VAD file" in r.stderr
+    r = run(C2 + ["-nr_mode", "fwss", "-vad", f"file={tmp_path / 'nope'}", "-S", str(tmp_path / "list")])
+    assert r.returncode == 255 and "Unable to open VAD file" in r.stderr

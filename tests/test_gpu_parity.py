@@ -948,3 +948,38 @@ def test_baseline_sizes_by_properties(Engine, name):
         one = eng.extract([u[eng.dims.wshift:].copy()])[0]   # any shift: the same rows to rounding
         assert one.shape[0] == full.shape[0] - 1 and rel_err(one[1:], full[2:]) <= TOL
     plan.close()
+
+
+@pytest.mark.parametrize("mode,fs", [("hwss", 8000), ("fwss", 8000), ("2fwss", 8000), ("fwss", 16000), ("2fwss", 16000)])
+def test_spectral_subtraction_with_decisions_from_a_file(Engine, tmp_path, mode, fs):
+    # -vad file=<f> (src/nr/nr.cc:205-209, 297-302): one byte per frame out of ONE stream for the whole list, every byte but NUL =
+    # speech; the engine reads the file at creation like hwssNR's constructor, the stream runs on from run to run
+    from ctucopy_amd import CtuError
+    utts = [synth_utt(300 + k, fs * 2 + 57 * k, fs=fs) for k in range(5)] + [np.zeros(fs // 100 * 2, np.int16)]  # the last one: no frame
+    base = f"-fs {fs} -format_in raw -format_out htk -preset mfcc -preem 0.97 -nr_mode {mode}".split()
+    if mode == "hwss":  # half-wave rectification under arbitrary decisions empties whole bands: band energies instead of their logarithms
+        base += ["-fea_kind", "spec"]
+    probe = Oracle(base + ["-vad", "burg"])
+    frames = [max(probe.num_frames(u.size), 0) for u in utts]
+    rng = np.random.default_rng(9)
+    stream = rng.choice(np.array([0, 0, 1, 7, ord("0")], np.uint8), sum(frames))
+    f = tmp_path / "vad.bin"
+    f.write_bytes(bytes(stream))
+    cfg = base + ["-vad", f"file={f}"]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    got = eng.extract(utts[:3]) + eng.extract(utts[3:])          # two runs: the stream (and the noise seed) carry over
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        if ref.size:
+            _assert_rows(g, ref, cfg)
+    with pytest.raises(CtuError, match="Unexpected end of VAD file"):   # the stream is spent
+        eng.extract(utts[:1])
+    eng.reset_chain()                                            # rewinds it (a new process)
+    again = eng.extract(utts[:3])
+    assert all(np.array_equal(x, y) for x, y in zip(again, got[:3]))
+    eng.set_vad_stream(bytes(stream[:5]) + b"\xff" + bytes(stream[5:]))   # 0xFF == EOF in the reference's signed char
+    with pytest.raises(CtuError, match="Unexpected end of VAD file"):
+        eng.extract(utts[:1])
+    with pytest.raises(CtuError, match="Unable to open VAD file"):
+        Engine(base + ["-vad", f"file={tmp_path / 'missing'}"])

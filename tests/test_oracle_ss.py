@@ -65,3 +65,38 @@ def test_detector_modes_the_reference_rejects():
         Oracle("-fs 8000 -preset mfcc -nr_mode hwss".split())
     with pytest.raises(OracleError, match="after filter bank"):
         Oracle("-fs 8000 -preset mfcc -nr_mode hwss -vad burg -nr_when afterFB".split())
+
+
+def test_vad_from_a_file_is_one_byte_stream_for_the_whole_list(tmp_path):
+    """-vad file=<f> (src/nr/nr.cc:205-209, 273, 297-302): `char vad = fgetc(fvad); if (vad != EOF) return bool(vad); else throw`.
+    One byte per frame; every byte but NUL is speech - an ASCII '0' too; the stream is opened by the constructor and runs on from
+    file to file; its end, and a byte 0xFF (equal to EOF in the signed char), end the run."""
+    a, b = synth.utterance(synth.SET_NOISY, 1, True), synth.utterance(synth.SET_NOISY, 4, True)
+    cfg = BASE[:-4] + ["-fea_kind", "spec", "-nr_mode", "fwss", "-nr_p", "0.9"]          # BASE without its -vad burg
+    ta, tb = Oracle(BASE).num_frames(a.size), Oracle(BASE).num_frames(b.size)
+    rng = np.random.default_rng(2)
+    dec = rng.integers(0, 2, ta + tb).astype(np.uint8)
+
+    def run(data, utts=(a, b)):
+        f = tmp_path / "v.bin"
+        f.write_bytes(bytes(data))
+        o = Oracle(cfg + ["-vad", "file=%s" % f])
+        return [o.process(u) for u in utts]
+
+    ra, rb = run(dec)
+    # file b reads its decisions where file a stopped: flipping the bytes behind a's changes b's rows and leaves a's alone
+    fa, fb = run(np.concatenate([dec[:ta], 1 - dec[ta:]]))
+    assert np.array_equal(fa, ra) and not np.array_equal(fb, rb)
+    # every byte but NUL is speech: 1, 2, '0' and '1' alike
+    for other in (2 * dec, np.where(dec, ord("1"), 0).astype(np.uint8), np.where(dec, ord("0"), 0).astype(np.uint8)):
+        assert all(np.array_equal(x, y) for x, y in zip(run(other), (ra, rb)))
+    assert all(np.array_equal(x, y) for x, y in zip(run(np.full(ta + tb, ord("0"), np.uint8)), run(np.ones(ta + tb, np.uint8))))
+    # noise frames update the estimate: all-NUL differs from all-speech, and with decisions = 0 everywhere fwss is a plain recursion
+    assert not np.array_equal(run(np.zeros(ta + tb, np.uint8))[0], run(np.ones(ta + tb, np.uint8))[0])
+    with pytest.raises(OracleError, match="Unexpected end of VAD file"):
+        run(dec[:ta + tb - 1])
+    with pytest.raises(OracleError, match="Unexpected end of VAD file"):
+        run(np.concatenate([dec[:5], [255], dec[5:]]).astype(np.uint8))
+    assert len(run(dec[:ta], (a,))) == 1                         # exactly enough for one file
+    with pytest.raises(OracleError, match="Unable to open VAD file"):
+        Oracle(cfg + ["-vad", "file=%s" % (tmp_path / "missing")])
