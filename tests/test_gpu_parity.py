@@ -854,7 +854,14 @@ def test_spectral_subtraction_chain_survives_between_runs(Engine):
                                  C2 + ["-nr_mode", "exten", "-nr_when", "afterFB", "-fea_kind", "logspec"],
                                  C3 + ["-nr_mode", "exten", "-nr_when", "afterFB"],
                                  C2 + ["-nr_when", "afterFB", "-fea_E", "on"],
-                                 "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -nr_mode exten -nr_when afterFB".split()])
+                                 "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -nr_mode exten -nr_when afterFB".split(),
+                                 # followed by the post-processing chains (src/io/batch.cc:122-130, 172-204): delta, stacking, CMS
+                                 C2 + ["-nr_mode", "exten", "-nr_when", "afterFB", "-fea_delta", "d_a"],
+                                 C2 + ["-nr_mode", "exten", "-nr_a", "2", "-nr_when", "afterFB", "-fea_E", "on", "-fea_delta", "d_a_t"],
+                                 C2 + ["-nr_mode", "exten", "-nr_when", "afterFB", "-fea_trap", "4"],
+                                 C2 + ["-nr_mode", "exten", "-nr_when", "afterFB", "-fea_Z_exp", "0.98"],
+                                 C3 + ["-nr_mode", "exten", "-nr_when", "afterFB", "-fea_delta", "d", "-fea_Z_block", "50"],
+                                 "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -nr_mode exten -nr_when afterFB -fea_delta d_a -fea_Z_exp 0.95".split()])
 def test_noise_reduction_after_the_filter_bank(Engine, cfg):
     fs = 8000 if "8000" in cfg else 16000
     from ctucopy_amd import synth
