@@ -1682,6 +1682,14 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                                pl->d_row_off.p, pl->n_utt, d_vad, e->vp);
             HIP_TRY(hipGetLastError());
         }
+        if (e->do_vad && d.o.vad_filter_order > 1) {
+            // A file with no more frames than the majority filter delays never gets the filter `ready` (src/vad/vad.h:126-136), so
+            // BATCH::flush_vad's loop does not start (src/vad/vad.cc:742-745, src/io/batch.cc:243-249): the reference writes neither a
+            // row nor a decision for it.  Its decision bytes become NUL ("nothing written"); ctu_engine_run_host reports 0 rows.
+            hipLaunchKernelGGL(vad_short_files_kernel, dim3((unsigned)((pl->n_utt + 255) / 256)), dim3(256), 0, s, d_vad, pl->d_row_off.p, pl->n_utt,
+                               (d.o.vad_filter_order - 1) / 2);
+            HIP_TRY(hipGetLastError());
+        }
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
@@ -1848,6 +1856,11 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm
                         }
                     if (rows_per_utt) rows_per_utt[i] = keep;
                 }
+            } else if (rows_per_utt) {
+                // a file the majority filter never got ready on (no more frames than its delay) writes no row (ctu_engine_run)
+                const int64_t delay = (d.o.vad_filter_order - 1) / 2;
+                for (int i = 0; i < pl->n_utt; i++)
+                    if (pl->frames[i] <= delay) rows_per_utt[i] = 0;
             }
         }
     } catch (const std::exception &ex) {

@@ -479,4 +479,14 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
     }
 }
 
+// Decisions of the files the majority filter never got `ready` on (src/vad/vad.h:126-136: no more frames than (order-1)/2): the
+// reference writes nothing for them - their bytes become NUL.
+__global__ void vad_short_files_kernel(unsigned char *vad, const int64_t *row_off, int n_utt, int delay) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_utt) return;
+    const int64_t r0 = row_off[i], T = row_off[i + 1] - r0;
+    if (T <= delay)
+        for (int64_t t = 0; t < T; t++) vad[r0 + t] = 0;
+}
+
 }  // namespace

@@ -315,5 +315,6 @@ class Engine:
         rows, vad, per = self.run_host(plan, plan.pack(utterances), want_vad=True)
         out = [rows[plan.row_off[i]:plan.row_off[i] + per[i]] for i in range(plan.n_utt)]
         vads = [vad[plan.row_off[i]:plan.row_off[i + 1]] for i in range(plan.n_utt)]
+        vads = [v[v != 0] for v in vads]  # NUL = nothing written (an utterance the majority filter never got ready on)
         plan.close()
         return (out, vads) if want_vad else out

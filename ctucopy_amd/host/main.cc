@@ -702,8 +702,10 @@ int real_main(int argc, char **argv) {
                         const Item &it = items[b->pos + i];
                         const Shard &sh = b->sh[b->where[i].first];
                         const size_t k = b->where[i].second;
-                        if (vad_files) {  // one ASCII '0'/'1' per frame (src/vad/vad.h:67-70)
-                            std::vector<uint8_t> v(sh.vad.begin() + sh.ro[k], sh.vad.begin() + sh.ro[k + 1]);
+                        if (vad_files) {  // one ASCII '0'/'1' per frame (src/vad/vad.h:67-70); NUL = nothing written (include/ctu_engine.h)
+                            std::vector<uint8_t> v;
+                            for (int64_t t = sh.ro[k]; t < sh.ro[k + 1]; t++)
+                                if (sh.vad[(size_t)t]) v.push_back(sh.vad[(size_t)t]);
                             write_file(it.fvad, v, "FileWriter: cannot open file!");
                         }
                         if (per_file) {

@@ -114,7 +114,9 @@ void ctu_host_free(void *);
  * least 16 utterances and 32 MiB in page-locked buffers go in eight utterance ranges on two streams, so the upload of a
  * range overlaps the kernels and the download of the previous one (environment CTU_HOST_CHUNKS=<n> overrides, 1 = one
  * range; the hwss / fwss / 2fwss chain always runs in one).  rows_per_utt (optional, n_utt entries) receives the number
- * of rows actually produced per utterance (< frames only with -vad_apply_mode drop). */
+ * of rows actually produced per utterance: < frames with -vad_apply_mode drop, and 0 for an utterance with no more frames than the VAD's
+ * majority filter delays ((vad_filter_order-1)/2: the filter never gets ready, src/vad/vad.h:126-136, and the reference writes neither a
+ * row nor a decision; the utterance's bytes in h_vad / d_vad are NUL then, '0' / '1' otherwise). */
 int ctu_engine_run_host(ctu_engine *, const ctu_plan *, const int16_t *h_pcm, float *h_rows, uint8_t *h_vad,
                         int64_t *rows_per_utt);
 

@@ -116,7 +116,8 @@ class Oracle:
             raise OracleError(lib().ctuo_error(self._h).decode())
         out = rows[:n].copy()
         if want_vad:
-            return out, vad[:T].copy()
+            v = vad[:T]
+            return out, v[v != 0].copy()  # '0' / '1' per decision written; none for a file the majority filter never got ready on
         return out
 
     def enhance(self, pcm):

@@ -479,3 +479,19 @@ def test_vad_decisions_from_a_file_through_the_cli(tmp_path):
     assert r.returncode == 255 and "Unexpected end of VAD file" in r.stderr
     r = run(C2 + ["-nr_mode", "fwss", "-vad", f"file={tmp_path / 'nope'}", "-S", str(tmp_path / "list")])
     assert r.returncode == 255 and "Unable to open VAD file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_one_frame_file_with_the_vad_writes_an_empty_htk_file_and_no_decision(tmp_path):
+    """A file with no more frames than the VAD's majority filter delays (default order 3: one frame) never gets the filter ready: the
+    reference writes a header with 0 frames and an empty VAD file for it (src/vad/vad.h:126-136, src/io/batch.cc:230-249)."""
+    from tests.util import C4, synth_utt
+    lines = []
+    for i, T in enumerate((1, 30)):
+        synth_utt(70 + i, 120 + 80 * T, fs=8000).astype("<i2").tofile(tmp_path / f"u{i}.raw")
+        lines.append(f"{tmp_path / f'u{i}.raw'} {tmp_path / f'u{i}.htk'} spk {tmp_path / f'u{i}.vad'}")
+    (tmp_path / "list").write_text("\n".join(lines) + "\n")
+    r = run(C4 + ["-S", str(tmp_path / "list")])
+    assert r.returncode == 0, r.stderr
+    assert struct.unpack("<I", (tmp_path / "u0.htk").read_bytes()[:4])[0] == 0 and (tmp_path / "u0.vad").read_bytes() == b""
+    assert struct.unpack("<I", (tmp_path / "u1.htk").read_bytes()[:4])[0] == 30 and len((tmp_path / "u1.vad").read_bytes()) == 30

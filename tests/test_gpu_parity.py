@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
-from tests.util import C1, C2, C3, C5, sig, synth_utt
+from tests.util import C1, C2, C3, C4, C5, sig, synth_utt
 
 pytestmark = pytest.mark.gpu
 
@@ -709,7 +709,8 @@ def test_many_ragged_utterances_walk_the_tile_chains(Engine, extra):
     eng, orc = Engine(cfg), Oracle(cfg)
     want_vad = "-vad_out_mode" in extra
     got = eng.extract(utts, want_vad=True)[0] if want_vad else eng.extract(utts)
-    assert [g.shape[0] for g in got] == frames
+    # with the VAD a one-frame file leaves the (order 3) majority filter unready and writes nothing (vad.h:126-136)
+    assert [g.shape[0] for g in got] == [0 if want_vad and f <= 1 else f for f in frames]
     for i in rng.choice(len(utts), 40, replace=False):  # the oracle is the slow side: check a random 40
         _assert_rows(got[i], orc.process(utts[i]), cfg)
 
@@ -990,3 +991,24 @@ def test_spectral_subtraction_with_decisions_from_a_file(Engine, tmp_path, mode,
         eng.extract(utts[:1])
     with pytest.raises(CtuError, match="Unable to open VAD file"):
         Engine(base + ["-vad", f"file={tmp_path / 'missing'}"])
+
+
+@pytest.mark.parametrize("order", [1, 3, 5])
+def test_files_shorter_than_the_majority_filter_delay_write_nothing(Engine, order):
+    # medianFilter gets `ready` only when a push finds (order-1)/2 decisions behind it (src/vad/vad.h:126-136); BATCH::flush_vad runs on
+    # that flag (src/vad/vad.cc:742-745): a file with no more frames than the delay leaves neither rows nor decisions.  The oracle's filter
+    # is pinned against the reference's own class (tests/test_oracle_median_ref.py).  Both the fused criterion and the separate kernels.
+    for cfg in (C4 + ["-vad_filter_order", str(order)],
+                C2 + "-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode adapt".split() + ["-vad_filter_order", str(order)]):
+        fs = 8000 if "8000" in cfg else 16000
+        hop, pre = fs // 100, fs * 25 // 1000 - fs // 100
+        utts = [synth_utt(90 + T, pre + hop * T, fs=fs) for T in (1, 2, 3, 40)]
+        eng, orc = Engine(cfg), Oracle(cfg)
+        got, vads = eng.extract(utts, want_vad=True)
+        for T, u, g, v in zip((1, 2, 3, 40), utts, got, vads):
+            ref, rv = orc.process(u, want_vad=True)
+            want = T if T > (order - 1) // 2 else 0
+            assert ref.shape[0] == want and g.shape[0] == want and len(rv) == want and len(v) == want, (order, T)
+            if want:
+                assert np.array_equal(np.asarray(v), np.asarray(rv))
+                _assert_rows(g, ref, cfg)
