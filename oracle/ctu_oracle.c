@@ -96,6 +96,11 @@ struct ctuo {
     unsigned char *vad_stream;
     long vad_len, vad_pos;
     int vad_from_file;
+    /* The VAD's majority filter lives as long as the process (one VAD object per BATCH): VAD::clean() = cleanFilter() resets `start`,
+     * `ready`, the ring and the decisions at the end of a file but NOT historyIdx / historySize (src/vad/vad.h:110-121).  The next
+     * file's pushes therefore land in ring slots that are out of phase with the slots its outputs are read from: its rows come out
+     * shifted, with an all-zero or a repeated row (pinned against the reference's own class, tests/test_oracle_median_ref.py). */
+    int med_hidx, med_hsize;
 };
 
 static void set_err(ctuo_t *c, const char *msg) {
@@ -942,6 +947,9 @@ long ctuo_num_frames(const ctuo_t *c, long n) {
     return (n - pre) / c->o.wshift;
 }
 
+void ctuo_set_vad_ring(ctuo_t *c, int hidx, int hsize) { c->med_hidx = hidx; c->med_hsize = hsize; }
+void ctuo_get_vad_ring(const ctuo_t *c, int *hidx, int *hsize) { *hidx = c->med_hidx; *hsize = c->med_hsize; }
+
 const char *ctuo_error(const ctuo_t *c) { return c->err; }
 const double *ctuo_hamming(const ctuo_t *c) { return c->W; }
 float ctuo_preem(const ctuo_t *c) { return c->o.preem; }
@@ -1395,6 +1403,8 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     if (do_vad) {
         vs.history = calloc(order, sizeof(int));
         vs.ring = calloc((size_t)order * vlen, sizeof(double));
+        vs.hidx = c->med_hidx % order;   /* what the previous file of this process left (0, 0 for the first) */
+        vs.hsize = c->med_hsize;
         if (!strcmp(o->vad_cri_mode, "cepdist")) {
             vs.csize = !strcmp(o->vad_cepdist_mode, "lpc") ? o->vad_lpc_coefs : c->nfea;
             vs.c0 = calloc(vs.csize, sizeof(double));
@@ -1828,15 +1838,20 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         /* `while (vad->flush_frame())` runs on the filter's `ready` (vad.cc:742-745), which only a push that found the history
          * full sets (vad.h:126-136): a file with no more frames than the filter delays - (order-1)/2 - never gets there, the loop
          * does not start, and neither a row nor a decision is written for it (pinned by tests/test_oracle_median_ref.py) */
-        while (vs.ready && vs.hsize > 0) {
-            vs.history[vs.hidx] = 0;
-            vs.hidx = (vs.hidx + 1) % order;
-            double sum = 0.0;
-            for (int i = 0; i < order; i++) sum += vs.history[i] ? 1.0 : 0.0;
-            const double *fo = vs.ring + (size_t)(vs.start % order) * vlen;
-            vs.start++;
-            int dec = (sum / (double)order) >= 0.5;
-            vs.hsize--;
+        for (;;) { /* `while (vad->flush_frame())`: VAD::flush_frame calls the filter's flush_frame and returns its `ready` */
+            int dec = 0;
+            const double *fo = NULL;
+            if (vs.hsize > 0) {
+                vs.history[vs.hidx] = 0;
+                vs.hidx = (vs.hidx + 1) % order;
+                double sum = 0.0;
+                for (int i = 0; i < order; i++) sum += vs.history[i] ? 1.0 : 0.0;
+                fo = vs.ring + (size_t)(vs.start % order) * vlen;
+                vs.start++;
+                dec = (sum / (double)order) >= 0.5;
+                vs.hsize--;
+            } else vs.ready = 0;
+            if (!vs.ready) break; /* also for a filter that never got ready: one flush_frame ran, nothing is written */
             if (vadout && strcmp(o->vad_out_mode, "none")) vadout[nvad] = dec ? '1' : '0';
             nvad++;
             if (!(!dec && !strcmp(o->vad_apply_mode, "drop"))) {
@@ -1845,6 +1860,8 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                 nrows++;
             }
         }
+        c->med_hidx = vs.hidx; /* VAD::clean() leaves both as they are */
+        c->med_hsize = vs.hsize;
     }
     if (is_trap && do_vad && !fail) { set_err(c, "oracle: trapdct together with VAD is not restated"); fail = 1; }
 

@@ -74,6 +74,11 @@ long ctuo_process(ctuo_t *, const int16_t *pcm, long nsamples, float *rows, unsi
 long ctuo_out_samples(const ctuo_t *, long nsamples);
 long ctuo_enhance(ctuo_t *, const int16_t *pcm, long nsamples, int16_t *out);
 
+/* The majority filter's historyIdx / historySize as the previous file of the process left them (src/vad/vad.h:110-121: cleanFilter does
+ * not reset them); (0, 0) = the first file of a process.  ctuo_process carries them from call to call. */
+void ctuo_set_vad_ring(ctuo_t *, int hidx, int hsize);
+void ctuo_get_vad_ring(const ctuo_t *, int *hidx, int *hsize);
+
 const char *ctuo_error(const ctuo_t *);
 
 /* Introspection used by the host-design tests. */

@@ -48,6 +48,8 @@ def lib():
         L.ctuo_out_samples.argtypes = [ctypes.c_void_p, ctypes.c_long]
         L.ctuo_enhance.restype = ctypes.c_long
         L.ctuo_enhance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+        L.ctuo_set_vad_ring.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.ctuo_get_vad_ring.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.ctuo_process.restype = ctypes.c_long
         L.ctuo_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
         L.ctuo_error.restype = ctypes.c_char_p
@@ -103,22 +105,37 @@ class Oracle:
     def num_frames(self, nsamples):
         return int(lib().ctuo_num_frames(self._h, int(nsamples)))
 
-    def process(self, pcm, want_vad=False):
-        """pcm: int16 array of one utterance -> float32 [rows, D] (and the VAD '0'/'1' bytes)."""
+    def process(self, pcm, want_vad=False, first_in_process=True):
+        """pcm: int16 array of one utterance -> float32 [rows, D] (and the VAD '0'/'1' bytes).
+
+        first_in_process: the VAD's majority filter starts as in a fresh process (historyIdx = historySize = 0); False keeps what the
+        previous call left, as the reference does from file to file (src/vad/vad.h:110-121; process_list)."""
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        if first_in_process:
+            lib().ctuo_set_vad_ring(self._h, 0, 0)
         T = self.num_frames(pcm.size)
         if T < 0:
             raise OracleError("IO: Signal shorter than one frame!")
-        rows = np.empty((max(T, 1), self.dims.D), dtype=np.float32)
-        vad = np.zeros(max(T, 1), dtype=np.uint8)
+        # a file can write more rows than it has frames: a majority filter left half drained by the file before it (list mode, orders >= 5)
+        rows = np.empty((T + 64, self.dims.D), dtype=np.float32)
+        vad = np.zeros(T + 64, dtype=np.uint8)
         n = lib().ctuo_process(self._h, pcm.ctypes.data, pcm.size, rows.ctypes.data, vad.ctypes.data)
         if n < 0:
             raise OracleError(lib().ctuo_error(self._h).decode())
         out = rows[:n].copy()
         if want_vad:
-            v = vad[:T]
-            return out, v[v != 0].copy()  # '0' / '1' per decision written; none for a file the majority filter never got ready on
+            return out, vad[vad != 0].copy()  # '0' / '1' per decision written; none for a file the majority filter never got ready on
         return out
+
+    def process_list(self, utterances, want_vad=False):
+        """The utterances as the files of ONE list of one process: the majority filter's ring index runs on from file to file."""
+        return [self.process(u, want_vad=want_vad, first_in_process=(i == 0)) for i, u in enumerate(utterances)]
+
+    def vad_ring(self):
+        """(historyIdx, historySize) the last processed file left behind."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        lib().ctuo_get_vad_ring(self._h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
 
     def enhance(self, pcm):
         """-format_out raw|wave: int16 samples of the enhanced utterance (what rawOUT/waveOUT write, host byte order)."""

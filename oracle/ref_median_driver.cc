@@ -38,4 +38,32 @@ int ref_median_run(int order, int nfeat, const double *feats, const unsigned cha
     return n;
 }
 
+// A list of files through ONE filter object, as the process keeps it (BATCH owns one VAD for the whole list): per file the pushes, the
+// flush loop, then VAD::clean() = cleanFilter() (src/io/batch.cc:292-295, src/vad/vad.cc:705-708) - which resets `start` and the ring but
+// neither historyIdx nor historySize.  feats are scalars here (nfeat = 1, the frame's own index + 1, so that 0 = an untouched ring slot);
+// out receives, per file, the values the writer would see; n_out[f] their count.
+void ref_median_list(int order, const int *frames, int n_files, double *out, int *n_out) {
+    Vec<double> feat(1);
+    Vec<double> *res = 0;
+    medianFilter f(order, &feat, &res);
+    f.cleanFilter();
+    long w = 0;
+    for (int k = 0; k < n_files; k++) {
+        int n = 0;
+        for (int t = 0; t < frames[k]; t++) {
+            feat[0] = t + 1;
+            f.push(true);
+            if (f.ready) { out[w++] = (*res)[0]; n++; }
+        }
+        for (;;) {
+            f.flush_frame();
+            if (!f.ready) break;
+            out[w++] = (*res)[0];
+            n++;
+        }
+        n_out[k] = n;
+        f.cleanFilter();
+    }
+}
+
 }

@@ -72,3 +72,55 @@ def test_order_one_is_the_identity():
     feats, vad0 = rng.standard_normal((50, 4)), rng.integers(0, 2, 50).astype(np.uint8)
     dec, out = _reference_filter(L, 1, feats, vad0)
     assert np.array_equal(dec, vad0) and np.array_equal(out, feats)
+
+
+def _ref_list(L, order, frames):
+    fr = np.array(frames, dtype=np.int32)
+    out = np.zeros(int(fr.sum()) + 2 * order * len(frames) + 8)
+    n = np.zeros(len(frames), dtype=np.int32)
+    L.ref_median_list.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.ref_median_list(order, fr.ctypes.data, len(frames), out.ctypes.data, n.ctypes.data)
+    res, w = [], 0
+    for k in range(len(frames)):
+        res.append(out[w:w + n[k]].astype(int))
+        w += n[k]
+    return res
+
+
+@pytest.mark.parametrize("order", [3, 5])
+def test_the_filter_ring_runs_on_from_file_to_file(order):
+    """One VAD object serves the whole list and VAD::clean() = cleanFilter() resets `start`, the ring and the decisions but neither
+    historyIdx nor historySize (src/vad/vad.h:110-121): the next file's vectors land in ring slots out of phase with the slots its outputs
+    are read from.  The reference class driven over lists of files (value = frame index + 1, 0 = an untouched slot) against the oracle's
+    list mode: which frame's vector each written row carries, all-zero rows and row counts included."""
+    L = _ref()
+    base = "-fs 8000 -format_in raw -format_out htk -preset mfcc -fea_kind spec -vad_out_mode vad -vad_cri_mode energy -vad_thr_mode adapt".split()
+    cfg = base + ["-vad_filter_order", str(order)]
+    rng = np.random.default_rng(order)
+    for trial in range(6):
+        frames = [int(x) for x in rng.integers(0, 12, 7)] + [9]
+        utts = [synth_utt(200 + 10 * trial + i, 120 + 80 * T + (0 if T else 40), fs=8000) for i, T in enumerate(frames)]
+        want = _ref_list(L, order, frames)
+        o = Oracle(cfg)
+        got = o.process_list(utts, want_vad=True)
+        alone = [Oracle(cfg).process(u) for u in utts]           # every file as the first of its own process: the undisturbed vectors
+        for k, (T, (rows, vad), src) in enumerate(zip(frames, got, want)):
+            assert rows.shape[0] == src.size == len(vad), (order, frames, k)
+            for r, t1 in zip(rows, src):
+                if t1 == 0:
+                    assert not r.any()                           # a ring slot this file has not written yet: zeros
+                else:
+                    # the frame's own vector; a file no longer than the delay writes nothing when alone, so take it from a longer run
+                    full = alone[k] if alone[k].shape[0] == T else None
+                    if full is not None:
+                        assert np.array_equal(r, full[t1 - 1]), (order, frames, k, t1)
+    # the first file of a process, and process() by default, start in phase
+    assert Oracle(cfg).vad_ring() == (0, 0)
+
+
+def test_reference_list_behaviour_at_the_default_order():
+    """What a user of the reference gets at -vad_filter_order 3 (its default): rows of a file shifted by one frame either way, depending on
+    the frame counts of the files in front of it."""
+    L = _ref()
+    assert [r.tolist() for r in _ref_list(L, 3, [6, 6, 6, 7])] == [[1, 2, 3, 4, 5, 6], [0, 1, 2, 3, 4, 5], [2, 3, 4, 5, 6, 4], [1, 2, 3, 4, 5, 6, 7]]
+    assert [r.tolist() for r in _ref_list(L, 3, [1, 6])] == [[], [2, 3, 4, 5, 6, 4]]
