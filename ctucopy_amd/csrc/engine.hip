@@ -155,6 +155,11 @@ struct ctu_plan {
     std::vector<std::unique_ptr<ctu_plan>> parts;
     std::vector<int> part_first;       // first utterance of every part, n_utt at the end
     int parts_for = 0;                 // the range count `parts` was built for (ctu_engine_run_host)
+    // VAD majority filter out of phase (ctu_plan_set_vad_ring): which frame's vector every written row carries (-1: an untouched ring
+    // slot = zeros; absolute row numbers), and a copy of the rows to gather from
+    std::vector<int> ring_hidx;        // per utterance, empty = all in phase
+    DevBuf<int> ring_src;              // [total_frames]
+    DevBuf<float> ring_tmp;            // [total_frames][D]
     hipStream_t part_stream[2] = {nullptr, nullptr};
     ~ctu_plan() {
         for (hipStream_t st : part_stream)
@@ -1307,6 +1312,72 @@ const int64_t *ctu_plan_row_offsets(const ctu_plan *p) { return p->row_off.data(
 int64_t ctu_plan_total_samples(const ctu_plan *p) { return p->total_samples; }
 int64_t ctu_plan_total_frames(const ctu_plan *p) { return p->total_frames; }
 
+void ctu_vad_ring_step(int32_t order, int64_t frames, int32_t *hidx, int32_t *hsize) {
+    // medianFilter::push / flush_frame / cleanFilter as VAD::process_frame, BATCH::flush_vad and VAD::clean drive them over one file
+    // (src/vad/vad.h:110-175, src/vad/vad.cc:692-699,705-708,742-745): cleanFilter resets neither historyIdx nor historySize
+    if (order < 1 || !hidx || !hsize) return;
+    const int delay = (order - 1) / 2;
+    int hi = ((*hidx % order) + order) % order, hs = *hsize;
+    bool ready = false;
+    for (int64_t t = 0; t < frames; t++) {
+        hi = (hi + 1) % order;
+        if (hs < delay) hs++;
+        else ready = true;
+    }
+    for (;;) {
+        if (hs > 0) {
+            hi = (hi + 1) % order;
+            hs--;
+        } else
+            ready = false;
+        if (!ready) break;
+    }
+    *hidx = hi;
+    *hsize = hs;
+}
+
+int ctu_plan_set_vad_ring(ctu_plan *pl, const int32_t *hidx) {
+    if (!pl) return CTU_ERR_INPUT;
+    ctu_engine *e = pl->eng;
+    const ctu::Design &d = *e->design;
+    pl->ring_hidx.clear();
+    if (!hidx || !e->do_vad || d.o.vad_filter_order <= 1) return CTU_OK;
+    const int order = d.o.vad_filter_order, delay = (order - 1) / 2;
+    bool any = false;
+    for (int i = 0; i < pl->n_utt; i++) any = any || (hidx[i] % order) != 0;
+    if (!any) return CTU_OK;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        pl->ring_hidx.assign(hidx, hidx + pl->n_utt);
+        // the ring per utterance: push t writes slot (hidx0 + t) % order; the k-th written row reads slot k % order - at push k + delay,
+        // or after the last push for the rows of the flush (src/vad/vad.h:126-175 with `start` reset by cleanFilter, historyIdx not)
+        std::vector<int> src((size_t)std::max<int64_t>(pl->total_frames, 1), -1);
+        std::vector<int> slot(order);
+        for (int i = 0; i < pl->n_utt; i++) {
+            const int64_t T = pl->frames[i], r0 = pl->row_off[i];
+            const int h0 = ((hidx[i] % order) + order) % order;
+            if (T <= delay) continue;  // nothing is written for it
+            std::fill(slot.begin(), slot.end(), -1);
+            int64_t k = 0;
+            for (int64_t t = 0; t < T; t++) {
+                slot[(size_t)((h0 + t) % order)] = (int)t;
+                if (t >= delay) {
+                    src[(size_t)(r0 + k)] = slot[(size_t)(k % order)] < 0 ? -1 : (int)(r0 + slot[(size_t)(k % order)]);
+                    k++;
+                }
+            }
+            for (; k < T; k++) src[(size_t)(r0 + k)] = slot[(size_t)(k % order)] < 0 ? -1 : (int)(r0 + slot[(size_t)(k % order)]);
+        }
+        pl->ring_src.upload(src);
+        if (pl->ring_tmp.n < (size_t)std::max<int64_t>(pl->total_frames, 1) * d.D) pl->ring_tmp.alloc((size_t)std::max<int64_t>(pl->total_frames, 1) * d.D);
+    } catch (const std::exception &ex) {
+        set_error(e, std::string("ENGINE: ") + ex.what());
+        pl->ring_hidx.clear();
+        return CTU_ERR_DEVICE;
+    }
+    return CTU_OK;
+}
+
 int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, float *d_rows, uint8_t *d_vad, void *stream) {
     if (!e || !pl || pl->eng != e) return CTU_ERR_INPUT;
     if (pl->n_tiles == 0) return CTU_OK;
@@ -1690,6 +1761,15 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                                (d.o.vad_filter_order - 1) / 2);
             HIP_TRY(hipGetLastError());
         }
+        if (e->do_vad && !pl->ring_hidx.empty() && pl->total_frames > 0) {
+            // the list behaviour of the reference's majority filter (ctu_plan_set_vad_ring): every column but the energy (which does not
+            // go through the ring, src/io/batch.cc:101-120) of row k := the vector of frame ring_src[k], or zeros
+            const size_t n = (size_t)pl->total_frames * d.D;
+            HIP_TRY(hipMemcpyAsync(pl->ring_tmp.p, d_rows, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(vad_ring_gather_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535u * 16)), dim3(256), 0, s, pl->ring_tmp.p, d_rows,
+                               pl->ring_src.p, (int64_t)pl->total_frames, d.D, d.o.fea_E ? (d.post_order > 0 ? d.D - 1 : d.e_slot) : -1);
+            HIP_TRY(hipGetLastError());
+        }
     } catch (const std::exception &ex) {
         set_error(e, std::string("ENGINE: ") + ex.what());
         return CTU_ERR_DEVICE;
@@ -1783,6 +1863,10 @@ int ctu_engine_run_host(ctu_engine *e, const ctu_plan *pl_, const int16_t *h_pcm
             for (int k = 0; k < np; k++) {
                 ctu_plan *sp = pl->parts[k].get();
                 hipStream_t st = pl->part_stream[k & 1];
+                if (e->do_vad) {  // a range is a plan of its own: it starts its utterances where the caller's plan does
+                    const int rc = ctu_plan_set_vad_ring(sp, pl->ring_hidx.empty() ? nullptr : pl->ring_hidx.data() + pl->part_first[k]);
+                    if (rc != CTU_OK) return rc;
+                }
                 if (sp->total_frames) {
                     if (sp->h_pcm.n < (size_t)sp->total_samples) sp->h_pcm.alloc((size_t)sp->total_samples);
                     if (sp->h_rows.n < (size_t)sp->total_frames * d.D) sp->h_rows.alloc((size_t)sp->total_frames * d.D);

@@ -489,4 +489,17 @@ __global__ void vad_short_files_kernel(unsigned char *vad, const int64_t *row_of
         for (int64_t t = 0; t < T; t++) vad[r0 + t] = 0;
 }
 
+// The reference's majority filter out of phase with its own ring (ctu_plan_set_vad_ring, engine.hip): row r of the output := the row
+// src[r] of the rows as computed (-1: zeros), every column but the energy's.
+__global__ void vad_ring_gather_kernel(const float *__restrict__ in, float *__restrict__ out, const int *__restrict__ src, int64_t total_rows, int D, int e_slot) {
+    const int64_t n = total_rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int c = (int)(i - r * D);
+        if (c == e_slot) continue;
+        const int sr = src[r];
+        out[i] = sr >= 0 ? in[(int64_t)sr * D + c] : 0.f;
+    }
+}
+
 }  // namespace

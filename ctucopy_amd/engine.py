@@ -32,7 +32,7 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_arena_layout", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_engine_set_vad_stream", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_engine_set_vad_stream", "ctu_vad_ring_step", "ctu_plan_set_vad_ring", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
 
@@ -78,6 +78,9 @@ def load_library():
     L.ctu_engine_run_host.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ctu_engine_reset_chain.argtypes = [vp]
     L.ctu_engine_set_vad_stream.argtypes = [vp, ctypes.c_char_p, i64]
+    L.ctu_vad_ring_step.restype = None
+    L.ctu_vad_ring_step.argtypes = [ctypes.c_int32, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.ctu_plan_set_vad_ring.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.ctu_decode_g711.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
     L.ctu_host_alloc.restype = vp
     L.ctu_host_alloc.argtypes = [ctypes.c_size_t]
@@ -160,6 +163,19 @@ class Plan:
         self.row_off = np.ctypeslib.as_array(L.ctu_plan_row_offsets(h), shape=(self.n_utt + 1,)).copy()
         self.total_samples = int(L.ctu_plan_total_samples(h))
         self.total_frames = int(L.ctu_plan_total_frames(h))
+
+    def set_vad_ring(self, hidx):
+        """The historyIdx of the VAD's majority filter every utterance starts with (None: all in phase): the reference's list behaviour,
+        see include/ctu_engine.h."""
+        L = load_library()
+        if hidx is None:
+            rc = L.ctu_plan_set_vad_ring(self._h, None)
+        else:
+            a = np.ascontiguousarray(hidx, dtype=np.int32)
+            assert a.size == self.n_utt
+            rc = L.ctu_plan_set_vad_ring(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        if rc != CTU_OK:
+            raise CtuError(rc, L.ctu_last_error(self.engine._h).decode())
 
     def pack(self, utterances):
         """int16 arena (numpy) holding the utterances at their planned offsets."""
@@ -309,9 +325,24 @@ class Engine:
     def kernel_name(self):
         return load_library().ctu_engine_kernel_name(self._h).decode()
 
-    def extract(self, utterances, want_vad=False):
-        """Convenience: list of int16 arrays -> list of [rows, D] float32 arrays (and the VAD byte strings)."""
+    def vad_ring_of_list(self, nsamples, order):
+        """historyIdx each file of a list starts with when the list is one process's (ctu_vad_ring_step from 0, 0)."""
+        L = load_library()
+        hi, hs = ctypes.c_int32(0), ctypes.c_int32(0)
+        out = []
+        for n in nsamples:
+            out.append(hi.value)
+            L.ctu_vad_ring_step(int(order), max(self.num_frames(int(n)), 0), ctypes.byref(hi), ctypes.byref(hs))
+        return out
+
+    def extract(self, utterances, want_vad=False, as_list_of_one_process=None):
+        """Convenience: list of int16 arrays -> list of [rows, D] float32 arrays (and the VAD byte strings).
+
+        as_list_of_one_process = the VAD's filter order: the utterances are the files of one list, the majority filter's ring index runs
+        on from file to file as in the reference (Plan.set_vad_ring)."""
         plan = self.plan([len(u) for u in utterances])
+        if as_list_of_one_process:
+            plan.set_vad_ring(self.vad_ring_of_list([len(u) for u in utterances], as_list_of_one_process))
         rows, vad, per = self.run_host(plan, plan.pack(utterances), want_vad=True)
         out = [rows[plan.row_off[i]:plan.row_off[i] + per[i]] for i in range(plan.n_utt)]
         vads = [vad[plan.row_off[i]:plan.row_off[i + 1]] for i in range(plan.n_utt)]

@@ -414,6 +414,7 @@ struct PinPool {
 struct Shard {
     std::vector<size_t> idx;      // positions in the batch, list order
     std::vector<int64_t> ns, so;  // samples per utterance, arena offsets (ctu_arena_layout)
+    std::vector<int32_t> hidx;    // VAD: the majority filter's ring index every utterance starts with (the list is one process's)
     int64_t total_samples = 0, total_frames = 0;
     PinBuf arena, rows;           // int16 in; float32 rows (or int16 samples with -format_out raw|wave) out
     std::vector<int64_t> ro, kept, nout;
@@ -438,6 +439,7 @@ void run_shard(ctu_engine *eng, Shard &sh, PinPool &pool, bool signal_out, bool 
     const int64_t *so = ctu_plan_sample_offsets(plan), *ro = ctu_plan_row_offsets(plan);
     if (ctu_plan_total_samples(plan) != sh.total_samples || !std::equal(sh.so.begin(), sh.so.end(), so))
         throw Fatal("ENGINE: internal: the plan's arena layout differs from ctu_arena_layout");
+    if (!sh.hidx.empty() && ctu_plan_set_vad_ring(plan, sh.hidx.data()) != CTU_OK) throw Fatal(ctu_last_error(eng));
     sh.total_frames = ctu_plan_total_frames(plan);
     sh.ro.assign(ro, ro + n + 1);
     sh.kept.assign(n, 0);
@@ -580,8 +582,12 @@ int real_main(int argc, char **argv) {
     Chan<std::unique_ptr<Batch>> to_engine(1), to_writer(1);
     std::atomic<bool> giving_up{false};
 
+    // The reference's VAD keeps its majority filter for the whole list and cleanFilter() does not reset its ring index between files
+    // (src/vad/vad.h:110-121): the rows of a file depend on the frame counts of the files in front of it (include/ctu_engine.h).
+    const bool vad_ring = d.has_vad && o.vad_filter_order > 1;
     std::thread reader([&] {
         size_t pos = 0;
+        int32_t ring_hidx = 0, ring_hsize = 0;
         while (pos < items.size() && !giving_up) {
             std::unique_ptr<Batch> b(new Batch);
             b->pos = pos;
@@ -626,11 +632,18 @@ int real_main(int argc, char **argv) {
                     load[g] += (size_t)ns[i];
                 }
                 b->where.resize(n);
+                std::vector<int32_t> hidx_of(n, 0);
+                if (vad_ring)
+                    for (size_t i = 0; i < n; i++) {  // list order
+                        hidx_of[i] = ring_hidx;
+                        ctu_vad_ring_step(o.vad_filter_order, std::max<int64_t>(ctu_num_frames(gpus[0].eng, ns[i]), 0), &ring_hidx, &ring_hsize);
+                    }
                 for (int g = 0; g < ngpu; g++) {
                     Shard &sh = b->sh[g];
                     std::sort(sh.idx.begin(), sh.idx.end());
                     for (size_t k = 0; k < sh.idx.size(); k++) {
                         sh.ns.push_back(ns[sh.idx[k]]);
+                        if (vad_ring) sh.hidx.push_back(hidx_of[sh.idx[k]]);
                         b->where[sh.idx[k]] = {g, k};
                     }
                     sh.so.resize(sh.ns.size() + 1);

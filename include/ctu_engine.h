@@ -136,6 +136,17 @@ int ctu_engine_reset_chain(ctu_engine *);
  * stream and rewinds it, ctu_engine_reset_chain rewinds it. */
 int ctu_engine_set_vad_stream(ctu_engine *, const unsigned char *bytes, int64_t n);
 
+/* The VAD's majority filter belongs to the process, not to the file: VAD::clean() = medianFilter::cleanFilter() resets `start`, the ring
+ * and the decisions at the end of a file but neither historyIdx nor historySize (src/vad/vad.h:110-121), so the vectors of the next file
+ * land in ring slots out of phase with the slots its rows are read from - its rows come out shifted by a frame or two, with an all-zero
+ * or a repeated row - depending on the frame counts of the files in front of it (decisions are not affected).  By default every
+ * utterance of a plan is treated as the first file of its own process (in phase).  A host that wants the reference's list behaviour
+ * walks its list with ctu_vad_ring_step (pure: the state after a file of `frames` frames; start from 0, 0) and hands each plan the
+ * historyIdx its utterances start with; the run then delivers the rows the reference would write.  bin/ctucopy does.  Not reproduced:
+ * a historySize left over by a file with no more frames than the delay, at filter orders of 5 and more. */
+void ctu_vad_ring_step(int32_t order, int64_t frames, int32_t *hidx, int32_t *hsize);
+int ctu_plan_set_vad_ring(ctu_plan *, const int32_t *hidx /* n_utt entries, or NULL: all in phase */);
+
 /* Timing of the last ctu_engine_run on this engine, measured with HIP events on the run's stream
  * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */
 float ctu_engine_last_kernel_ms(ctu_engine *);

@@ -165,3 +165,21 @@ def test_arena_layout_rule():
     bad = np.array([5, -1], dtype=np.int64)
     assert L.ctu_arena_layout(bad.ctypes.data_as(ctypes.POINTER(i64)), 2, None) < 0
     assert L.ctu_arena_layout(None, 3, None) < 0
+
+
+def test_vad_ring_step_follows_the_filter_from_file_to_file():
+    """ctu_vad_ring_step (pure): historyIdx / historySize of the VAD's majority filter after a file, as the oracle's list mode leaves them
+    (pinned against the reference's own class in tests/test_oracle_median_ref.py)."""
+    from tests.util import synth_utt
+    L = ceng.load_library()
+    rng = np.random.default_rng(8)
+    for order in (1, 3, 5, 7):
+        cfg = "-fs 8000 -format_in raw -format_out htk -preset mfcc -vad_out_mode vad -vad_cri_mode energy -vad_thr_mode adapt".split() + ["-vad_filter_order", str(order)]
+        o = Oracle(cfg)
+        hi, hs = ctypes.c_int32(0), ctypes.c_int32(0)
+        first = True
+        for T in [int(x) for x in rng.integers(0, 9, 12)]:
+            o.process(synth_utt(3, 120 + 80 * T + (0 if T else 40), fs=8000), first_in_process=first)
+            first = False
+            L.ctu_vad_ring_step(order, T, ctypes.byref(hi), ctypes.byref(hs))
+            assert (hi.value, hs.value) == o.vad_ring(), (order, T)

@@ -495,3 +495,30 @@ def test_one_frame_file_with_the_vad_writes_an_empty_htk_file_and_no_decision(tm
     assert r.returncode == 0, r.stderr
     assert struct.unpack("<I", (tmp_path / "u0.htk").read_bytes()[:4])[0] == 0 and (tmp_path / "u0.vad").read_bytes() == b""
     assert struct.unpack("<I", (tmp_path / "u1.htk").read_bytes()[:4])[0] == 30 and len((tmp_path / "u1.vad").read_bytes()) == 30
+
+
+@pytest.mark.gpu
+def test_vad_list_through_the_cli_is_the_reference_list(tmp_path):
+    """bin/ctucopy walks its list as one process like the reference: the VAD's majority filter keeps its ring index from file to file
+    (src/vad/vad.h:110-121), also across the batches of the host loop and over two engines."""
+    from tests.util import C4, synth_utt
+    frames = [17, 9, 31, 8, 1, 25, 14, 40, 22, 13]
+    utts, lines = [], []
+    for i, T in enumerate(frames):
+        u = synth_utt(500 + i, 120 + 80 * T + 3 * i, fs=8000)
+        u.astype("<i2").tofile(tmp_path / f"u{i}.raw")
+        utts.append(u)
+        lines.append(f"{tmp_path / f'u{i}.raw'} {tmp_path / f'u{i}.htk'} spk {tmp_path / f'u{i}.vad'}")
+    (tmp_path / "list").write_text("\n".join(lines) + "\n")
+    ref = Oracle(C4).process_list(utts, want_vad=True)
+    for extra in ([], ["--gpus", "2", "--gpu-map", "0,0"]):
+        r = run(C4 + ["-S", str(tmp_path / "list")] + extra)
+        assert r.returncode == 0, r.stderr
+        for i, (rows, rv) in enumerate(ref):
+            raw = (tmp_path / f"u{i}.htk").read_bytes()
+            n = struct.unpack("<I", raw[:4])[0]
+            assert n == rows.shape[0] and (tmp_path / f"u{i}.vad").read_bytes() == bytes(rv), (extra, i)
+            if n:
+                got = np.frombuffer(raw[12:], dtype="<f4").reshape(n, -1)
+                assert np.array_equal(~got.any(axis=1), ~rows.any(axis=1))
+                assert np.all(np.abs(got - rows) <= 1e-3 * np.maximum(np.abs(rows), 1.0)), (extra, i)

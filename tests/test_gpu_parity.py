@@ -1012,3 +1012,39 @@ def test_files_shorter_than_the_majority_filter_delay_write_nothing(Engine, orde
             if want:
                 assert np.array_equal(np.asarray(v), np.asarray(rv))
                 _assert_rows(g, ref, cfg)
+
+
+@pytest.mark.parametrize("cfg,order", [(C4, 3),
+                                       (C2 + "-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode adapt".split(), 3),
+                                       (C2 + "-fea_delta d_a -fea_E on -vad_out_mode vad -vad_cri_mode energy -vad_thr_mode dyn".split(), 3),
+                                       (C2 + "-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode adapt -vad_filter_order 5".split(), 5),
+                                       (C4 + ["-vad_apply_mode", "drop"], 3)])
+def test_the_list_behaviour_of_the_reference_vad_filter(Engine, cfg, order):
+    # One VAD object serves the reference's whole list and cleanFilter() does not reset the majority filter's ring index between files
+    # (src/vad/vad.h:110-121): a file's rows come out shifted by a frame or two, with an all-zero or a repeated row, depending on the frame
+    # counts of the files in front of it.  The oracle's list mode is pinned against the reference's own class
+    # (tests/test_oracle_median_ref.py); the engine reproduces it when the plan is told where each utterance's ring starts
+    # (ctu_plan_set_vad_ring) and treats every utterance as the first of its process otherwise.
+    fs = 8000 if "8000" in cfg else 16000
+    hop, pre = fs // 100, fs * 25 // 1000 - fs // 100
+    # 0: a file without a frame; 1: one the filter never gets ready on (not behind a delta chain, which wants window + 2 frames, nor at
+    # order 5, where it would leave historySize half drained: the corner the ABI does not reproduce)
+    frames = [17, 9, 31, 8, 1 if order == 3 and "-fea_delta" not in cfg else 12, 25, 0, 14, 40]
+    utts = [synth_utt(400 + i, pre + hop * T + (hop // 2 if T == 0 else 3 * i), fs=fs) for i, T in enumerate(frames)]
+    if "drop" in cfg:  # dropped rows need decisions of both kinds: the noisy set's miniatures
+        from ctucopy_amd import synth
+        utts = [synth.utterance_c(synth.SET_NOISY, k, True) for k in range(7)]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    got, vads = eng.extract(utts, want_vad=True, as_list_of_one_process=order)
+    ref = orc.process_list(utts, want_vad=True)
+    alone, _ = eng.extract(utts, want_vad=True)
+    differs = 0
+    for i, (g, v, (r, rv)) in enumerate(zip(got, vads, ref)):
+        assert g.shape == r.shape and np.array_equal(np.asarray(v), np.asarray(rv)), (i, g.shape, r.shape)
+        if r.size:
+            zero_rows = ~r.any(axis=1)
+            assert np.array_equal(~g.any(axis=1), zero_rows)     # an untouched ring slot comes out as zeros in both
+            _assert_rows(g[~zero_rows], r[~zero_rows], cfg)
+            differs += not np.array_equal(g, alone[i])
+    assert differs >= (1 if "drop" in cfg else 2)                # the list does change the rows of the files behind the first
+    assert np.array_equal(got[0], alone[0])                      # ... not those of the first
