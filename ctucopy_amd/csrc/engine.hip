@@ -236,7 +236,6 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.post_order > 0) {
         if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "delta / stacking on non-cepstral kinds (the reference sizes the chain as fea_ncepcoefs+1, src/fea/fea_delta.cc:22-28)";
         if (!o.fea_c0) return "delta / stacking without -fea_c0 (the reference's writers leave slots of the row unwritten, src/io/out.cc:190-201)";
-        if (o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea") return "the `fea` VAD criterion together with delta / stacking";
         int wsum = 0;
         for (int j = 0; j < d.post_order; j++) {
             if (d.post_w[j] > 16) return "delta / stacking window above 16 frames";
@@ -1067,7 +1066,7 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             vp.adapt_q = o.vad_adapt_q; vp.adapt_za = o.vad_adapt_za; vp.dyn_perc = o.vad_dyn_perc; vp.dyn_min = o.vad_dyn_min;
             vp.qmaxinc = o.vad_dyn_qmaxinc; vp.qmaxdec = o.vad_dyn_qmaxdec; vp.qmindec = o.vad_dyn_qmindec; vp.qmininc = o.vad_dyn_qmininc;
             vp.perc_init = o.vad_perc_init; vp.adapt_init = o.vad_adapt_init; vp.dyn_init = o.vad_dyn_init;
-            vp.D = d.D; vp.ncep = o.fea_ncepcoefs; vp.c0_slot = d.row_slot.empty() ? -1 : d.row_slot[0];
+            vp.D = d.D; vp.ncep = o.fea_ncepcoefs; vp.c0_slot = d.post_stack ? -2 : (d.row_slot.empty() ? -1 : d.row_slot[0]);  // -2: stacked rows keep the internal order (c0 first)
             vp.delay = 0;
             for (int j = 0; j < d.post_order; j++) vp.delay += d.post_w[j];
             vp.e_slot = o.fea_E ? (d.post_order > 0 ? d.D - 1 : d.e_slot) : -1;

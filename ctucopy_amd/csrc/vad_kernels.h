@@ -452,11 +452,14 @@ __global__ __launch_bounds__(64) void vad_decide_kernel(const double *__restrict
                 const int f = e / nc, i = e - f * nc;
                 stage[e] = ci_all[(r0 + min(tb + f + vp.delay, T - 1)) * nc + i];
             }
-        } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131)
+        } else {  // internal vector order: c0 first, then c1..cN (src/fea/fea_impl.cc:104-131).  Behind a delta / stacking chain the `fea`
+                  // mode reads the vector OUT sees at this call - the chain's output, whose first block is the frame that comes out - so,
+                  // unlike the two criteria above, it is not ahead of the row by the chain's delay
             for (int e = lane; e < nt * nc; e += 64) {
                 const int f = e / nc, i = e - f * nc;
                 const float *row = rows + (r0 + tb + f) * vp.D;
-                stage[e] = i == 0 ? (vp.c0_slot >= 0 ? (double)row[vp.c0_slot] : 0.0) : (double)row[i - 1];
+                // -fea_trap rows are the internal vector as it stands (the writers fall back to the straight copy, src/io/out.cc:182)
+                stage[e] = vp.c0_slot == -2 ? (double)row[i] : (i == 0 ? (vp.c0_slot >= 0 ? (double)row[vp.c0_slot] : 0.0) : (double)row[i - 1]);
             }
         }
         __syncthreads();

@@ -1048,3 +1048,23 @@ def test_the_list_behaviour_of_the_reference_vad_filter(Engine, cfg, order):
             differs += not np.array_equal(g, alone[i])
     assert differs >= (1 if "drop" in cfg else 2)                # the list does change the rows of the files behind the first
     assert np.array_equal(got[0], alone[0])                      # ... not those of the first
+
+
+@pytest.mark.parametrize("extra", [["-fea_delta", "d_a"], ["-fea_delta", "d_a_t", "-fea_E", "on"], ["-fea_trap", "3"], ["-fea_delta", "d_a", "-fea_Z_exp", "0.98"],
+                                   ["-fea_delta", "d", "-vad_filter_order", "5", "-vad_thr_mode", "dyn"]])
+@pytest.mark.parametrize("base", ["mfcc", "plpc"])
+def test_vad_feature_criterion_behind_delta_and_stacking_chains(Engine, base, extra):
+    # -vad_cepdist_mode fea takes the vector OUT sees at the call (src/vad/vad.cc:220-226): behind a delta chain its first block is the
+    # frame that comes out (not the newest input frame the other criteria look at), after CMS; stacked rows are the internal vector as
+    # it stands (c0 first: the writers' straight copy, src/io/out.cc:182).  Decisions byte for byte.
+    cfg = (C2 if base == "mfcc" else C3) + "-vad_out_mode vad -vad_cri_mode cepdist -vad_cepdist_mode fea -vad_thr_mode adapt".split() + extra
+    utts = [sig("CS0"), synth_utt(41, 50000), synth_utt(42, 240 + 160 * 9)]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    got, vads = eng.extract(utts, want_vad=True)
+    ones = 0
+    for u, g, v in zip(utts, got, vads):
+        r, rv = orc.process(u, want_vad=True)
+        assert g.shape == r.shape and np.array_equal(np.asarray(v), np.asarray(rv))
+        _assert_rows(g, r, cfg)
+        ones += int((np.asarray(v) == ord("1")).sum())
+    assert ones > 100                                            # the detector does fire
