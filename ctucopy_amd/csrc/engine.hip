@@ -229,7 +229,7 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., plain chain)";
     }
     if (o.nr_when_afterFB) {
-        if (o.do_vad() || d.signal_out) return "-nr_when afterFB together with VAD or signal output";
+        if (d.signal_out) return "-nr_when afterFB together with signal output";
         if (d.B > 64) return "-nr_when afterFB with more than 64 bands";
     }
     if (o.rasta) return "-nr_rasta";

@@ -1068,3 +1068,22 @@ def test_vad_feature_criterion_behind_delta_and_stacking_chains(Engine, base, ex
         _assert_rows(g, r, cfg)
         ones += int((np.asarray(v) == ord("1")).sum())
     assert ones > 100                                            # the detector does fire
+
+
+@pytest.mark.parametrize("fs", [16000, 8000])
+@pytest.mark.parametrize("extra", ["-vad_cri_mode energy -vad_thr_mode adapt", "-vad burg -vad_cri_mode cepdist -vad_cepdist_mode lpc -vad_thr_mode adapt",
+                                   "-vad_cri_mode cepdist -vad_cepdist_mode fea -vad_thr_mode adapt", "-vad_cri_mode energy -vad_thr_mode perc -vad_apply_mode drop",
+                                   "-vad_cri_mode energy -vad_thr_mode dyn -fea_delta d_a"])
+def test_noise_reduction_after_the_filter_bank_with_the_vad(Engine, fs, extra):
+    # -nr_when afterFB leaves the spectrum alone (the NR works on the band energies, src/io/batch.cc:207-210), so the VAD's criteria see the
+    # spectrum as the transform left it; decisions byte for byte, rows in the exten class
+    from ctucopy_amd import synth
+    cfg = f"-fs {fs} -format_in raw -format_out htk -preset mfcc -preem 0.97 -nr_mode exten -nr_when afterFB -vad_out_mode vad".split() + extra.split()
+    utts = [synth_utt(61, fs * 2, fs=fs), synth_utt(62, fs // 100 * 70 + fs // 40, fs=fs), synth.utterance_c(synth.SET_NOISY if fs == 8000 else synth.SET_SPEECH, 6, True)]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    got, vads = eng.extract(utts, want_vad=True)
+    for u, g, v in zip(utts, got, vads):
+        r, rv = orc.process(u, want_vad=True)
+        assert g.shape == r.shape and np.array_equal(np.asarray(v), np.asarray(rv))
+        if r.size:
+            _assert_rows(g, r, cfg)
