@@ -82,7 +82,6 @@ def test_unsupported_configurations_are_reported_not_approximated():
                 C2 + ["-fea_kind", "spec", "-fea_Z_exp", "500"],
                 C2 + ["-fea_delta", "d_a", "-fea_c0", "off"], C2 + ["-fea_kind", "logspec", "-fea_delta", "d"],
                 C2 + ["-fea_delta", "d", "-d_win", "17"],
-                C2 + "-vad_out_mode vad -vad_cri_mode cepdist -vad_cepdist_mode fea -fea_delta d".split(),   # the `fea` criterion on delayed vectors
                 C2 + ["-w", "300"],                               # 4800 samples: an 8192-point FFT
                 C2 + ["-w", "40", "-nr_mode", "exten"],           # noise reduction with a 1024-point FFT
                 C2 + ["-remove_dc1", "on", "-w", "25", "-s", "2"]):   # 12 frames over a sample
