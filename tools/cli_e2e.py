@@ -13,7 +13,10 @@ sys.path.insert(0, ROOT)
 from ctucopy_amd import synth  # noqa: E402
 
 FLAGS = {"S-MFCC": ["-fs", "16000", "-format_in", "raw", "-format_out", "htk", "-preset", "mfcc", "-preem", "0.97"],
-         "S-NOISY": ["-fs", "8000", "-format_in", "raw", "-format_out", "htk", "-preset", "mfcc", "-nr_mode", "exten", "-nr_a", "2"]}
+         "S-NOISY": ["-fs", "8000", "-format_in", "raw", "-format_out", "htk", "-preset", "mfcc", "-nr_mode", "exten", "-nr_a", "2"],
+         # C4 with its VAD: a four-column list (the VAD files go beside the HTK files)
+         "S-NOISY-VAD": ["-fs", "8000", "-format_in", "raw", "-format_out", "htk", "-preset", "mfcc", "-nr_mode", "exten", "-nr_a", "2", "-vad", "burg", "-vad_out_mode", "vad",
+                         "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "lpc", "-vad_thr_mode", "adapt"]}
 
 
 def main():
@@ -29,7 +32,7 @@ def main():
     os.makedirs(din, exist_ok=True)
     os.makedirs(dout, exist_ok=True)
     idx = list(range(a.utts))
-    sid = synth.SET_NOISY if a.set == "S-NOISY" else synth.SET_SPEECH
+    sid = synth.SET_NOISY if a.set.startswith("S-NOISY") else synth.SET_SPEECH
     ns = synth.lengths(sid, idx)
     off = np.zeros(a.utts + 1, dtype=np.int64)
     off[1:] = np.cumsum((np.asarray(ns) + 7) // 8 * 8)
@@ -42,7 +45,10 @@ def main():
             p = os.path.join(din, "u%05d.raw" % i)
             if not os.path.exists(p) or os.path.getsize(p) != 2 * ns[i]:
                 arena[off[i]:off[i] + ns[i]].tofile(p)
-            f.write("%s %s\n" % (p, os.path.join(dout, "u%05d.htk" % i)))
+            if a.set.endswith("-VAD"):
+                f.write("%s %s spk %s\n" % (p, os.path.join(dout, "u%05d.htk" % i), os.path.join(dout, "u%05d.vad" % i)))
+            else:
+                f.write("%s %s\n" % (p, os.path.join(dout, "u%05d.htk" % i)))
     fs = synth.fs_of(sid)
     win, hop = fs * 25 // 1000, fs // 100
     frames = int(sum((n - (win - hop)) // hop for n in ns))
