@@ -248,7 +248,9 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (!o.fea_c0) return "CMVN without -fea_c0 (c0 is part of the statistics but not of the written row)";
         if (d.post_stack) return "CMVN on stacked vectors";
         if (d.cms) return "CMVN together with CMS (the reference warns and lets CMVN win, src/io/opts.cc:262-264)";
-        if (o.do_vad()) return "VAD together with CMVN";
+        // the statistics are taken over every frame and the VAD runs on the normalised vectors of the last pass (src/io/batch.cc:193-204,230-241):
+        // a criterion on those vectors would need the statistics first
+        if (o.do_vad() && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea") return "the `fea` VAD criterion together with CMVN";
     }
     if (d.cms) {
         if (d.kind != ctu::FeaKind::Dctc && d.kind != ctu::FeaKind::Lpc) return "CMS on non-cepstral kinds (the reference walks fea_ncepcoefs+1 entries whatever the vector holds, src/fea/post_impl.cc:203-240)";
@@ -1335,6 +1337,27 @@ void ctu_vad_ring_step(int32_t order, int64_t frames, int32_t *hidx, int32_t *hs
     *hsize = hs;
 }
 
+int64_t ctu_vad_ring_rows(int32_t order, int64_t frames, int32_t hidx0, int32_t *src) {
+    // the ring of one file: push t writes slot (hidx0 + t) % order; the k-th written row reads slot k % order - at push k + delay, or after
+    // the last push for the rows of the flush (src/vad/vad.h:126-175 with `start` reset by cleanFilter, historyIdx not)
+    if (order < 1 || frames < 0) return CTU_ERR_INPUT;
+    const int delay = (order - 1) / 2;
+    if (frames <= delay) return 0;  // the filter never gets ready: nothing is written
+    if (!src) return frames;
+    const int h0 = ((hidx0 % order) + order) % order;
+    std::vector<int32_t> slot((size_t)order, -1);
+    int64_t k = 0;
+    for (int64_t t = 0; t < frames; t++) {
+        slot[(size_t)((h0 + t) % order)] = (int32_t)t;
+        if (t >= delay) {
+            src[k] = slot[(size_t)(k % order)];
+            k++;
+        }
+    }
+    for (; k < frames; k++) src[k] = slot[(size_t)(k % order)];
+    return frames;
+}
+
 int ctu_plan_set_vad_ring(ctu_plan *pl, const int32_t *hidx) {
     if (!pl) return CTU_ERR_INPUT;
     ctu_engine *e = pl->eng;
@@ -1348,24 +1371,14 @@ int ctu_plan_set_vad_ring(ctu_plan *pl, const int32_t *hidx) {
     try {
         HIP_TRY(hipSetDevice(e->device));
         pl->ring_hidx.assign(hidx, hidx + pl->n_utt);
-        // the ring per utterance: push t writes slot (hidx0 + t) % order; the k-th written row reads slot k % order - at push k + delay,
-        // or after the last push for the rows of the flush (src/vad/vad.h:126-175 with `start` reset by cleanFilter, historyIdx not)
         std::vector<int> src((size_t)std::max<int64_t>(pl->total_frames, 1), -1);
-        std::vector<int> slot(order);
+        std::vector<int32_t> rel;
         for (int i = 0; i < pl->n_utt; i++) {
             const int64_t T = pl->frames[i], r0 = pl->row_off[i];
-            const int h0 = ((hidx[i] % order) + order) % order;
             if (T <= delay) continue;  // nothing is written for it
-            std::fill(slot.begin(), slot.end(), -1);
-            int64_t k = 0;
-            for (int64_t t = 0; t < T; t++) {
-                slot[(size_t)((h0 + t) % order)] = (int)t;
-                if (t >= delay) {
-                    src[(size_t)(r0 + k)] = slot[(size_t)(k % order)] < 0 ? -1 : (int)(r0 + slot[(size_t)(k % order)]);
-                    k++;
-                }
-            }
-            for (; k < T; k++) src[(size_t)(r0 + k)] = slot[(size_t)(k % order)] < 0 ? -1 : (int)(r0 + slot[(size_t)(k % order)]);
+            rel.assign((size_t)T, -1);
+            ctu_vad_ring_rows(order, T, hidx[i], rel.data());
+            for (int64_t k = 0; k < T; k++) src[(size_t)(r0 + k)] = rel[(size_t)k] < 0 ? -1 : (int)(r0 + rel[(size_t)k]);
         }
         pl->ring_src.upload(src);
         if (pl->ring_tmp.n < (size_t)std::max<int64_t>(pl->total_frames, 1) * d.D) pl->ring_tmp.alloc((size_t)std::max<int64_t>(pl->total_frames, 1) * d.D);

@@ -32,7 +32,7 @@ class Dims(ctypes.Structure):
 EXPORTS = ["ctu_engine_create", "ctu_engine_destroy", "ctu_create_error", "ctu_last_error", "ctu_engine_dims",
            "ctu_config_dims", "ctu_config_table", "ctu_num_frames", "ctu_plan_create", "ctu_plan_destroy", "ctu_plan_sample_offsets",
            "ctu_plan_row_offsets", "ctu_arena_layout", "ctu_plan_total_samples", "ctu_plan_total_frames", "ctu_engine_run",
-           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_engine_set_vad_stream", "ctu_vad_ring_step", "ctu_plan_set_vad_ring", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
+           "ctu_engine_run_host", "ctu_host_alloc", "ctu_host_free", "ctu_engine_reset_chain", "ctu_engine_set_vad_stream", "ctu_vad_ring_step", "ctu_plan_set_vad_ring", "ctu_vad_ring_rows", "ctu_decode_g711", "ctu_engine_last_kernel_ms", "ctu_engine_kernel_name", "ctu_cmvn_cols", "ctu_cmvn_accumulate", "ctu_cmvn_apply",
            "ctu_cmvn_accumulate_host", "ctu_cmvn_apply_host", "ctu_plan_out_samples", "ctu_engine_run_signal",
            "ctu_engine_run_signal_host"]
 
@@ -81,6 +81,8 @@ def load_library():
     L.ctu_vad_ring_step.restype = None
     L.ctu_vad_ring_step.argtypes = [ctypes.c_int32, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.ctu_plan_set_vad_ring.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    L.ctu_vad_ring_rows.restype = i64
+    L.ctu_vad_ring_rows.argtypes = [ctypes.c_int32, i64, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     L.ctu_decode_g711.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
     L.ctu_host_alloc.restype = vp
     L.ctu_host_alloc.argtypes = [ctypes.c_size_t]

@@ -537,6 +537,15 @@ int real_main(int argc, char **argv) {
     // engines, one per GPU
     std::vector<const char *> cargs;
     for (auto &a : args) cargs.push_back(a.c_str());
+    // CMVN together with the VAD (src/io/batch.cc:193-204,230-241): the statistics are taken over every frame (the passes that sum do not
+    // call save_frame, so the VAD does not see them), the last pass normalises a vector and THEN hands it to save_frame - the VAD's ring,
+    // its decision, the drop.  The engine therefore delivers every row (apply mode none) and this loop does the VAD's part on the
+    // normalised rows: the ring's phase along the list, the rows a short file does not write, the dropped frames.
+    const bool cmvn_vad = (o.stat_cmvn || o.apply_cmvn) && o.do_vad();
+    if (cmvn_vad) {
+        cargs.push_back("-vad_apply_mode");
+        cargs.push_back("none");
+    }
     std::vector<Gpu> gpus(ngpu);
     for (int g = 0; g < ngpu; g++)
         if (ctu_engine_create((int)cargs.size(), cargs.data(), gpu_map.empty() ? g : gpu_map[g], &gpus[g].eng) != CTU_OK) throw Fatal(ctu_create_error());
@@ -570,6 +579,7 @@ int real_main(int argc, char **argv) {
     }
     std::vector<std::vector<float>> all_rows(cmvn ? items.size() : 0);
     std::vector<int64_t> all_ns(cmvn ? items.size() : 0);
+    std::vector<std::vector<uint8_t>> all_vads(cmvn_vad ? items.size() : 0);
 
     // ---- the pipeline: reader -> engines (this thread) -> writer, one batch in each at a time
     const size_t batch_samples = (size_t)batch_mib << 19;  // samples of PCM per batch (default 1 GiB)
@@ -584,7 +594,7 @@ int real_main(int argc, char **argv) {
 
     // The reference's VAD keeps its majority filter for the whole list and cleanFilter() does not reset its ring index between files
     // (src/vad/vad.h:110-121): the rows of a file depend on the frame counts of the files in front of it (include/ctu_engine.h).
-    const bool vad_ring = d.has_vad && o.vad_filter_order > 1;
+    const bool vad_ring = d.has_vad && o.vad_filter_order > 1 && !cmvn_vad;  // with CMVN the ring acts on the normalised rows: below
     std::thread reader([&] {
         size_t pos = 0;
         int32_t ring_hidx = 0, ring_hsize = 0;
@@ -701,9 +711,14 @@ int real_main(int argc, char **argv) {
                     for (size_t i = 0; i < n; i++) {
                         int64_t nr;
                         const float *r = rows_of(i, nr);
-                        all_rows[b->pos + i].assign(r, r + nr * d.row_floats);
                         const Shard &sh = b->sh[b->where[i].first];
-                        all_ns[b->pos + i] = sh.ns[b->where[i].second];
+                        const size_t k = b->where[i].second;
+                        if (cmvn_vad) {  // every frame's row counts for the statistics, also those of a file the VAD writes nothing for
+                            nr = sh.ro[k + 1] - sh.ro[k];
+                            all_vads[b->pos + i].assign(sh.vad.begin() + sh.ro[k], sh.vad.begin() + sh.ro[k + 1]);
+                        }
+                        all_rows[b->pos + i].assign(r, r + nr * d.row_floats);
+                        all_ns[b->pos + i] = sh.ns[k];
                     }
                 } else {
                     const bool vad_files = d.has_vad && o.vad_out_mode != "none";
@@ -881,6 +896,9 @@ int real_main(int argc, char **argv) {
             }
             std::fclose(f);
         }
+        if (!o.apply_cmvn && cmvn_vad && o.vad_out_mode != "none")  // statistics only: VAD::new_file still opens every file's VAD output
+            for (const Item &it : items)
+                if (!it.fvad.empty()) write_file(it.fvad, std::vector<uint8_t>(), "FileWriter: cannot open file!");
         if (o.apply_cmvn) {
             std::vector<std::string> errs(ngpu);
             std::vector<std::thread> th;
@@ -898,12 +916,45 @@ int real_main(int argc, char **argv) {
             std::vector<std::pair<int, size_t>> where(items.size());  // (gpu, position in that GPU's shard)
             for (int g = 0; g < ngpu; g++)
                 for (size_t k = 0; k < sh[g].idx.size(); k++) where[sh[g].idx[k]] = {g, k};
+            int32_t ring_hidx = 0, ring_hsize = 0;  // the VAD's majority filter along the list (this is the only pass that pushes into it)
+            std::vector<float> vrows;
+            std::vector<int32_t> src;
             for (size_t i = 0; i < items.size(); i++) {
                 const int g = where[i].first;
                 const size_t k = where[i].second;
                 const int64_t *ro = ctu_plan_row_offsets(sh[g].plan);
-                const int64_t nr = ro[k + 1] - ro[k];
+                int64_t nr = ro[k + 1] - ro[k];
                 const float *r = sh[g].rows.data() + (size_t)ro[k] * d.row_floats;
+                if (cmvn_vad) {
+                    // what BATCH::save_frame does with the normalised vector (src/io/batch.cc:230-241): through the majority filter's ring -
+                    // whose index the previous files of the list have left somewhere (include/ctu_engine.h) -, the decision, the drop.  The
+                    // energy column does not go through the ring (the engine has already moved it to the row the writer reads it with).
+                    const int64_t T = nr, D = d.row_floats;
+                    const int e_col = o.fea_E ? (int)D - 1 : -1;
+                    src.assign((size_t)std::max<int64_t>(T, 1), -1);
+                    const int64_t n_out = ctu_vad_ring_rows(o.vad_filter_order, T, ring_hidx, src.data());
+                    ctu_vad_ring_step(o.vad_filter_order, T, &ring_hidx, &ring_hsize);
+                    const std::vector<uint8_t> &v = all_vads[i];
+                    std::vector<uint8_t> dec;
+                    vrows.clear();
+                    for (int64_t q = 0; q < n_out; q++) {
+                        const uint8_t b = v[(size_t)q];
+                        if (b) dec.push_back(b);
+                        if (o.vad_apply_mode == "drop" && b != '1') continue;
+                        const size_t at = vrows.size();
+                        vrows.resize(at + (size_t)D, 0.f);
+                        for (int c = 0; c < (int)D; c++) {
+                            if (c == e_col) vrows[at + c] = r[(size_t)q * D + c];
+                            else if (src[(size_t)q] >= 0) vrows[at + c] = r[(size_t)src[(size_t)q] * D + c];
+                        }
+                    }
+                    if (o.vad_out_mode != "none") {
+                        if (items[i].fvad.empty()) throw Fatal("VAD::new_file(): invalid filename!");
+                        write_file(items[i].fvad, dec, "FileWriter: cannot open file!");
+                    }
+                    nr = (int64_t)(vrows.size() / (size_t)D);
+                    r = vrows.data();
+                }
                 if (ark) ark->add(items[i].fout, r, nr, d.row_floats);
                 else if (pf) pf->add(r, nr, d.row_floats);
                 else write_htk(items[i].fout, r, nr, d);

@@ -146,6 +146,10 @@ int ctu_engine_set_vad_stream(ctu_engine *, const unsigned char *bytes, int64_t 
  * a historySize left over by a file with no more frames than the delay, at filter orders of 5 and more. */
 void ctu_vad_ring_step(int32_t order, int64_t frames, int32_t *hidx, int32_t *hsize);
 int ctu_plan_set_vad_ring(ctu_plan *, const int32_t *hidx /* n_utt entries, or NULL: all in phase */);
+/* The same mapping for one file on its own (pure; what ctu_plan_set_vad_ring applies on the device): the number of rows the file writes - its
+ * frames, or 0 when it has no more frames than the filter delays - and, if src is not NULL, for each of them the frame whose vector it carries
+ * (-1: an untouched ring slot, zeros).  For hosts that pass rows through stages of their own between the engine and the writer (CMVN). */
+int64_t ctu_vad_ring_rows(int32_t order, int64_t frames, int32_t hidx0, int32_t *src);
 
 /* Timing of the last ctu_engine_run on this engine, measured with HIP events on the run's stream
  * around the dominant (front-end) kernel; blocks until that run has finished.  Returns < 0 if none. */

@@ -522,3 +522,54 @@ def test_vad_list_through_the_cli_is_the_reference_list(tmp_path):
                 got = np.frombuffer(raw[12:], dtype="<f4").reshape(n, -1)
                 assert np.array_equal(~got.any(axis=1), ~rows.any(axis=1))
                 assert np.all(np.abs(got - rows) <= 1e-3 * np.maximum(np.abs(rows), 1.0)), (extra, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("apply_mode", ["none", "drop"])
+def test_cmvn_together_with_the_vad(tmp_path, apply_mode):
+    """-apply_cmvn with the VAD on (src/io/batch.cc:193-204,230-241): the passes that sum the statistics never call save_frame, so the
+    statistics are over every frame; the last pass normalises a vector and then hands it to save_frame - the VAD's ring (whose index runs on
+    along the list), its decision, the drop.  Expected: the oracle's rows and decisions of every file on its own, numpy CMVN over all of
+    them, then the ring mapping (ctu_vad_ring_rows, itself checked against the oracle's list mode and the reference's class) and the drop."""
+    import ctypes
+    from ctucopy_amd import engine as ceng
+    from ctucopy_amd import synth
+    from oracle.oracle import cmvn_apply, cmvn_slot_columns, cmvn_stats
+    from tests.util import C4
+    cfg = C4 + ["-vad_apply_mode", apply_mode]
+    utts = [synth.utterance_c(synth.SET_NOISY, k, True) for k in range(6)] + [np.zeros(120 + 80, np.int16) + 3]   # the last: one frame
+    spk = [0, 1, 0, 1, 1, 0, 1]
+    lines = []
+    for i, u in enumerate(utts):
+        u.astype("<i2").tofile(tmp_path / f"u{i}.raw")
+        lines.append(f"{tmp_path / f'u{i}.raw'} {tmp_path / f'u{i}.htk'} spk{spk[i]} {tmp_path / f'u{i}.vad'}")
+    (tmp_path / "list").write_text("\n".join(lines) + "\n")
+    r = run(cfg + ["-apply_cmvn", str(tmp_path / "stat"), "-S", str(tmp_path / "list")])
+    assert r.returncode == 0, r.stderr
+    # expected
+    plain = C4 + ["-vad_apply_mode", "none", "-vad_filter_order", "1"]      # every frame's row, undelayed; decisions do not depend on the filter...
+    orc1, orc = Oracle(plain), Oracle(C4 + ["-vad_apply_mode", "none"])     # ... and the filtered decisions of each file on its own
+    rows = [orc1.process(u) for u in utts]
+    dec = [np.asarray(orc.process(u, want_vad=True)[1]) for u in utts]
+    cols = cmvn_slot_columns(12, 1)
+    mean, var, _ = cmvn_stats(rows, np.array(spk), 2, cols)
+    L = ceng.load_library()
+    hi, hs = ctypes.c_int32(0), ctypes.c_int32(0)
+    for i, (u, rw) in enumerate(zip(utts, rows)):
+        T = rw.shape[0]
+        norm = cmvn_apply(rw, spk[i], mean, var, cols)
+        src = np.full(max(T, 1), -1, dtype=np.int32)
+        n_out = L.ctu_vad_ring_rows(3, T, hi.value, src.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        L.ctu_vad_ring_step(3, T, ctypes.byref(hi), ctypes.byref(hs))
+        assert n_out == len(dec[i])
+        want = np.stack([norm[src[q]] if src[q] >= 0 else np.zeros(13, np.float32) for q in range(n_out)]) if n_out else np.zeros((0, 13), np.float32)
+        if apply_mode == "drop" and n_out:
+            want = want[dec[i] == ord("1")]
+        raw = (tmp_path / f"u{i}.htk").read_bytes()
+        n = struct.unpack("<I", raw[:4])[0]
+        assert n == want.shape[0], (i, n, want.shape)
+        assert (tmp_path / f"u{i}.vad").read_bytes() == bytes(dec[i])
+        if n:
+            got = np.frombuffer(raw[12:], dtype="<f4").reshape(n, 13)
+            assert np.array_equal(~got.any(axis=1), ~want.any(axis=1))
+            assert np.all(np.abs(got - want) <= 2e-3 * np.maximum(np.abs(want), 1.0)), (i, float(np.abs(got - want).max()))
