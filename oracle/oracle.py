@@ -131,6 +131,10 @@ class Oracle:
         """The utterances as the files of ONE list of one process: the majority filter's ring index runs on from file to file."""
         return [self.process(u, want_vad=want_vad, first_in_process=(i == 0)) for i, u in enumerate(utterances)]
 
+    def set_vad_ring(self, hidx, hsize=0):
+        """Start the next process(..., first_in_process=False) where a list's earlier files left the majority filter."""
+        lib().ctuo_set_vad_ring(self._h, int(hidx), int(hsize))
+
     def vad_ring(self):
         """(historyIdx, historySize) the last processed file left behind."""
         a, b = ctypes.c_int(0), ctypes.c_int(0)
