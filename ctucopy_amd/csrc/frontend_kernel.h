@@ -28,6 +28,12 @@ namespace {
 #ifndef CTU_DUAL
 #define CTU_DUAL 1      // the two passes of the 512-point mode side by side in the headline instantiation (see DUAL below)
 #endif
+#ifndef CTU_PK
+#define CTU_PK 1        // 1: DUAL with the two passes in the halves of packed registers (v_pk_*_f32 for all of phase 1's arithmetic); 0: scalar lock step (round 3)
+#endif
+#ifndef CTU_ABL
+#define CTU_ABL 0       // diagnostic builds only (wrong results): bit 0 no lane-0 selects in the untangle, 1 no mean removal, 2 no imaginary
+#endif                  // transpose, 3 no mirror fetch, 4 no P stores of the mirror half, 5 no inter-stage twiddles, 6 no phase 2, 7 no second DFT: what a unit of VALU / LDS work costs
 #ifndef CTU_BURG_UNROLL2
 #define CTU_BURG_UNROLL2 0  // 1: the two lattices of a 16-lane group unrolled into one block (the scheduler may interleave them)
 #endif
@@ -191,6 +197,118 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         // is bound by dependent latency (LDS round trips, transcendental-free but long FMA chains) at four waves per SIMD,
         // not by issue.  The plain cepstral chain only (the headline instantiation).
         constexpr bool DUAL = CTU_DUAL && MODE == 0 && GEN == GEN_PLAIN && MD && !VX && NZ < 16 && !VF && !SS && !SY;
+        if constexpr (DUAL && CTU_PK) {
+            // The two passes as the two halves of packed registers: every add / multiply / FMA of phase 1 is a v_pk_*_f32 that
+            // serves slots 0-3 and 4-7 together (kernel_common.h: cx2).  Same statements as the scalar DUAL block below.
+            if (nv > 0) {
+                cx2 v[16];
+                const int f0 = slot0 + fg, f1 = f0 + 4;
+                const int c0 = f0 < nvalid ? f0 : nvalid - 1, c1 = f1 < nvalid ? f1 : nvalid - 1;  // duplicates are never stored
+                const bool st0 = (l16 == 0) && (rec.t0 + c0 == 0), st1 = (l16 == 0) && (rec.t0 + c1 == 0);
+                {
+                    const int16_t *x0p = p.pcm + rec.sbase + (int64_t)c0 * p.wshift + 2 * l16 - 2;
+                    const int16_t *x1p = p.pcm + rec.sbase + (int64_t)c1 * p.wshift + 2 * l16 - 2;
+                    pcm4 q0[NZ], q1[NZ];
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) q0[j] = *reinterpret_cast<const pcm4 *>(x0p + 32 * j);
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) q1[j] = *reinterpret_cast<const pcm4 *>(x1p + 32 * j);
+                    v2f dcp[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // four partial sums: a packed result cannot feed the next instruction
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        const float4 w4 = lc[(LC_WIN + 2 * j) >> 2];  // two rows of window pairs per float4
+                        const float w0 = (j & 1) ? w4.z : w4.x, w1 = (j & 1) ? w4.w : w4.y;
+                        v2f xm = {(float)(int16_t)(q0[j].lo >> 16), (float)(int16_t)(q1[j].lo >> 16)};
+                        const v2f x0 = {(float)(int16_t)(q0[j].hi & 0xffffu), (float)(int16_t)(q1[j].hi & 0xffffu)};
+                        const v2f x1 = {(float)(int16_t)(q0[j].hi >> 16), (float)(int16_t)(q1[j].hi >> 16)};
+                        if (j == 0) {  // first sample of the file: history is 0
+                            xm.x = st0 ? 0.f : xm.x;
+                            xm.y = st1 ? 0.f : xm.y;
+                        }
+                        const v2f y0 = (x0 - xm * p.preem) * w0, y1 = (x1 - x0 * p.preem) * w1;
+                        v[j] = cx2{y0, y1};
+                        dcp[j & 1] += y0;
+                        dcp[2 + (j & 1)] += y1;
+                    }
+                    const v2f dc = (dcp[0] + dcp[1]) + (dcp[2] + dcp[3]);
+#pragma unroll
+                    for (int j = NZ; j < 16; j++) v[j] = cx2{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+                    // mean of the windowed frame over `window` samples (src/io/in.cc:375-382); rows < NZ-1 are fully inside
+                    const v2f m = v2f{row16_allreduce_add(dc.x), row16_allreduce_add(dc.y)} * p.inv_window;
+                    const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
+                    const float mx = ((NZ - 1) & 1) ? mk.z : mk.x, my = ((NZ - 1) & 1) ? mk.w : mk.y;
+#pragma unroll
+                    for (int j = 0; j < NZ - 1; j++) {
+                        v[j].x -= m;
+                        v[j].y -= m;
+                    }
+                    v[NZ - 1].x -= m * mx;
+                    v[NZ - 1].y -= m * my;
+                }
+                dft16(v);
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
+                    v[2 * h + 1] = cmul_s(v[2 * h + 1], tw.x, tw.y);
+                    if (2 * h + 2 < 16) v[2 * h + 2] = cmul_s(v[2 * h + 2], tw.z, tw.w);
+                }
+                {   // both transposes at once through the wave's eight rows (layout: CTU_ADDTID16_P)
+                    const uint32_t sa = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lvoid_t *)Pw);
+                    const uint32_t rd = (uint32_t)(size_t)(lvoid_t *)(Pw + 129 * l16 + 16 * fg);
+#define CTU_E_XA(i) v[i].x.x
+#define CTU_E_XB(i) v[i].x.y
+#define CTU_E_YA(i) v[i].y.x
+#define CTU_E_YB(i) v[i].y.y
+                    __builtin_amdgcn_wave_barrier();
+                    CTU_ADDTID16_P(CTU_E_XA, sa, 0);
+                    CTU_ADDTID16_P(CTU_E_XB, sa, 256);
+                    v2f re[16], im[16];
+                    CTU_READ2_PAIRS16(re, rd);
+                    CTU_ADDTID16_P(CTU_E_YA, sa, 0);
+                    CTU_ADDTID16_P(CTU_E_YB, sa, 256);
+                    CTU_READ2_PAIRS16(im, rd);
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; n2++) v[n2] = cx2{re[n2], im[n2]};
+                    __builtin_amdgcn_wave_barrier();
+#undef CTU_E_XA
+#undef CTU_E_XB
+#undef CTU_E_YA
+#undef CTU_E_YB
+                }
+                dft16(v);
+                float *pr0 = Pw + fg * PSTRIDE, *pr1 = Pw + (4 + fg) * PSTRIDE;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) {
+                    const float4 u4q = ltw4[8 + (k2 >> 1)];
+                    const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
+                    const int k = l16 + 16 * k2;
+                    v2f br = {mirror_fetch(v[15 - k2].x.x, partner), mirror_fetch(v[15 - k2].x.y, partner)};
+                    v2f bi = {mirror_fetch(v[15 - k2].y.x, partner), mirror_fetch(v[15 - k2].y.y, partner)};
+                    if (l16 == 0) {
+                        br = v[(16 - k2) & 15].x;
+                        bi = v[(16 - k2) & 15].y;
+                    }
+                    const v2f ar = v[k2].x, ai = v[k2].y;
+                    const v2f sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                    const v2f tr = di * wr + dr * wi;
+                    const v2f ti = di * wi - dr * wr;
+                    const v2f ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
+                    // the untangle's 1/4 is in the window (the engine scales this instantiation's table by 1/2: ctu_engine::half_window)
+                    const v2f pk = ur * ur + ui * ui, pm = vr * vr + vi * vi;
+                    pr0[k] = pk.x;
+                    pr1[k] = pk.y;
+                    pr0[256 - k] = pm.x;
+                    pr1[256 - k] = pm.y;
+                }
+                if (l16 == 0) {  // bin 128 is its own mirror (no 1/4 there: the halved window is undone); bin 0 floor (src/io/in.cc:390)
+                    const v2f a = v[8].x * 2.f, b = v[8].y * 2.f;
+                    const v2f p128 = a * a + b * b;
+                    pr0[128] = p128.x;
+                    pr1[128] = p128.y;
+                    pr0[0] = pr1[0] = 1e-10f;
+                }
+            }
+        } else
         if constexpr (DUAL) {
             if (nv > 0) {
                 float2 v0[16], v1[16];
@@ -231,7 +349,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     const float4 mk = lc[(LC_MASK + 2 * (NZ - 1)) >> 2];
                     const float mx = ((NZ - 1) & 1) ? mk.z : mk.x, my = ((NZ - 1) & 1) ? mk.w : mk.y;
 #pragma unroll
-                    for (int j = 0; j < NZ - 1; j++) {
+                    for (int j = 0; j < ((CTU_ABL & 2) ? 1 : NZ - 1); j++) {
                         v0[j].x -= m0;
                         v0[j].y -= m0;
                         v1[j].x -= m1;
@@ -245,7 +363,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 dft16(v0);
                 dft16(v1);
 #pragma unroll
-                for (int h = 0; h < 8; h++) {
+                for (int h = 0; h < ((CTU_ABL & 32) ? 1 : 8); h++) {
                     const float4 tw = ltw4[h];  // (k1 = 2h+1, k1 = 2h+2)
                     v0[2 * h + 1] = cmul(v0[2 * h + 1], make_float2(tw.x, tw.y));
                     v1[2 * h + 1] = cmul(v1[2 * h + 1], make_float2(tw.x, tw.y));
@@ -254,36 +372,59 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                         v1[2 * h + 2] = cmul(v1[2 * h + 2], make_float2(tw.z, tw.w));
                     }
                 }
+#ifdef CTU_PAD_SALU  // diagnostic builds: what N more scalar / vector / LDS instructions per step cost (results unchanged)
+                {
+                    uint32_t pad_ = 0;
+                    asm volatile(".rept %c1\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(pad_) : "n"(CTU_PAD_SALU) : "scc");
+                }
+#endif
+#ifdef CTU_PAD_VALU
+                {
+                    float pad_ = 0.f;
+                    asm volatile(".rept %c1\n\tv_add_f32 %0, %0, %0\n\t.endr" : "+v"(pad_) : "n"(CTU_PAD_VALU));
+                }
+#endif
+#ifdef CTU_PAD_LDS
+                {
+                    f32x4 pad_;
+                    asm volatile(".rept %c2\n\tds_read_b128 %0, %1\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pad_) : "v"((uint32_t)(size_t)(lvoid_t *)(ltw + 4 * lane)), "n"(CTU_PAD_LDS) : "memory");
+                }
+#endif
+                float *pr0 = Pw + fg * PSTRIDE, *pr1 = Pw + (4 + fg) * PSTRIDE;
+                auto untangle = [&](const float2 (&v)[16], float *prow, int k2, float wr, float wi) {
+                    const int k = l16 + 16 * k2;
+                    float br = (CTU_ABL & 8) ? v[15 - k2].x : mirror_fetch(v[15 - k2].x, partner);
+                    float bi = (CTU_ABL & 8) ? v[15 - k2].y : mirror_fetch(v[15 - k2].y, partner);
+                    if (!(CTU_ABL & 1) && l16 == 0) {
+                        br = v[(16 - k2) & 15].x;
+                        bi = v[(16 - k2) & 15].y;
+                    }
+                    const float ar = v[k2].x, ai = v[k2].y;
+                    const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
+                    const float tr = wr * di + wi * dr;
+                    const float ti = wi * di - wr * dr;
+                    const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
+                    // the untangle's 1/4 is in the window (the engine scales this instantiation's table by 1/2: ctu_engine::half_window)
+                    if (CTU_ABL & 16) prow[k] = (ur * ur + ui * ui) + (vr * vr + vi * vi);
+                    else {
+                        prow[k] = ur * ur + ui * ui;
+                        prow[256 - k] = vr * vr + vi * vi;
+                    }
+                };
                 // both transposes at once: slots 0-3 through the wave's rows 0-3, slots 4-7 through rows 4-7 (their own
                 // spectra land there afterwards)
                 wave_transpose16_dual(v0, v1, (uint32_t)(size_t)(lvoid_t *)Pw, (uint32_t)(size_t)(lvoid_t *)scratch,
                                       Pw + 65 * l16 + 16 * fg, scratch + 65 * l16 + 16 * fg);
-                dft16(v0);
-                dft16(v1);
-                float *pr0 = Pw + fg * PSTRIDE, *pr1 = Pw + (4 + fg) * PSTRIDE;
+                if (!(CTU_ABL & 128)) {
+                    dft16(v0);
+                    dft16(v1);
+                }
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) {
                     const float4 u4q = ltw4[8 + (k2 >> 1)];
                     const float wr = (k2 & 1) ? u4q.z : u4q.x, wi = (k2 & 1) ? u4q.w : u4q.y;
-                    const int k = l16 + 16 * k2;
-                    auto untangle = [&](const float2 (&v)[16], float *prow) {
-                        float br = mirror_fetch(v[15 - k2].x, partner);
-                        float bi = mirror_fetch(v[15 - k2].y, partner);
-                        if (l16 == 0) {
-                            br = v[(16 - k2) & 15].x;
-                            bi = v[(16 - k2) & 15].y;
-                        }
-                        const float ar = v[k2].x, ai = v[k2].y;
-                        const float sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
-                        const float tr = wr * di + wi * dr;
-                        const float ti = wi * di - wr * dr;
-                        const float ur = sr + tr, ui = si + ti, vr = sr - tr, vi = si - ti;
-                        // the untangle's 1/4 is in the window (the engine scales this instantiation's table by 1/2: ctu_engine::half_window)
-                        prow[k] = ur * ur + ui * ui;
-                        prow[256 - k] = vr * vr + vi * vi;
-                    };
-                    untangle(v0, pr0);
-                    untangle(v1, pr1);
+                    untangle(v0, pr0, k2, wr, wi);
+                    untangle(v1, pr1, k2, wr, wi);
                 }
                 if (l16 == 0) {  // bin 128 is its own mirror (no 1/4 there: the halved window is undone); bin 0 floor (src/io/in.cc:390)
                     const float a0 = 2.f * v0[8].x, b0 = 2.f * v0[8].y, a1 = 2.f * v1[8].x, b1 = 2.f * v1[8].y;
@@ -875,7 +1016,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         // ================= phase 2 (wave-local): lane = (frame, band group) =================
         // The step's 8 frames x 8 band groups.  Bands are dealt to (slot, group) cells by the host so that the
         // 8 bands of a slot have similar widths; every group walks the same number of 4-bin chunks per slot.
-        if (o_dbg != 1 && !o_skip_phase2 && nv > 0) {
+        if (o_dbg != 1 && !o_skip_phase2 && nv > 0 && !(CTU_ABL & 64)) {
             // lane -> (frame f8, group g).  MD: lane = f8 + 8 h + 16 kk with g = kk + 4 h, the B-operand layout of the MFMA
             const int f8 = MD ? (lane & 7) : (lane >> 3), g = MD ? (((lane >> 3) & 1) * 4 + (lane >> 4)) : (lane & 7);
             const int fslot = slot0 + f8;

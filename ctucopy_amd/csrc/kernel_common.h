@@ -144,6 +144,48 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k = 0; k < 16; k++) v[k] = t[k];
 }
 
+// Two-lane packed arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): the two passes of a step run in lock step, so
+// pass A's value and pass B's value of every quantity share a 64-bit register pair and every add / multiply / FMA of the
+// transform serves both.  Element-wise only (no swizzles between the halves: the compiler would spend moves on them);
+// scalars - twiddles, window weights - are broadcast by op_sel.  A packed instruction issues in ~1.7x the time of a plain
+// one (tools/probes/valu_rate.hip) for twice the work.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct cx2 {
+    v2f x, y;  // real parts of (pass A, pass B), imaginary parts of (pass A, pass B)
+};
+__device__ __forceinline__ cx2 cmul_s(cx2 a, float wr, float wi) {  // both passes times the same twiddle
+    return cx2{a.x * wr - a.y * wi, a.x * wi + a.y * wr};
+}
+__device__ __forceinline__ void bfly4(cx2 &p0, cx2 &p1, cx2 &p2, cx2 &p3) {
+    const cx2 s02{p0.x + p2.x, p0.y + p2.y}, d02{p0.x - p2.x, p0.y - p2.y};
+    const cx2 s13{p1.x + p3.x, p1.y + p3.y}, d13{p1.x - p3.x, p1.y - p3.y};
+    p0 = cx2{s02.x + s13.x, s02.y + s13.y};
+    p2 = cx2{s02.x - s13.x, s02.y - s13.y};
+    p1 = cx2{d02.x + d13.y, d02.y - d13.x};  // d02 - i*d13
+    p3 = cx2{d02.x - d13.y, d02.y + d13.x};  // d02 + i*d13
+}
+__device__ __forceinline__ void dft16(cx2 (&v)[16]) {  // as dft16(float2[16]) above, statement for statement
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; b++) bfly4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    v[5] = cmul_s(v[5], C1, -S1);
+    v[6] = cx2{(v[6].x + v[6].y) * R2, (v[6].y - v[6].x) * R2};
+    v[7] = cmul_s(v[7], S1, -C1);
+    v[9] = cx2{(v[9].x + v[9].y) * R2, (v[9].y - v[9].x) * R2};
+    v[10] = cx2{v[10].y, -v[10].x};
+    v[11] = cx2{(v[11].y - v[11].x) * R2, -(v[11].x + v[11].y) * R2};
+    v[13] = cmul_s(v[13], S1, -C1);
+    v[14] = cx2{(v[14].y - v[14].x) * R2, -(v[14].x + v[14].y) * R2};
+    v[15] = cmul_s(v[15], -C1, S1);
+#pragma unroll
+    for (int c = 0; c < 4; c++) bfly4(v[4 * c + 0], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    cx2 t[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = v[4 * (k & 3) + (k >> 2)];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = t[k];
+}
+
 // LDS stores of one dword per lane at  M0 + offset + 4 * lane  (ds_write_addtid_b32): linear in the lane number, which is
 // what the transposes write (16 k1-rows of [frame slot][n2], 260 bytes apart).  M0 is compiler-reserved (it may hold an
 // offset of the compiler's own, e.g. for register spills) and an asm statement's write to it is invisible to the compiler:
@@ -165,6 +207,46 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
                        "v"(V[15].C), "s"(BASE)                                                                                      \
                      : "memory");                                                                                                    \
     } while (0)
+
+// The same for sixteen arbitrary float expressions E(i), i = 0..15 (the halves of packed pairs), rows 516 bytes apart
+// starting OFF bytes behind BASE: the layout of the packed transpose (frontend_kernel.h, CTU_PK) - row k1 of pass A at
+// dword 129 k1, of pass B at 129 k1 + 64, so that one ds_read2_b32 (offset0 = n2, offset1 = 64 + n2) returns the
+// (pass A, pass B) pair of an element into one register pair, and lane (k1, fg) reading dword 129 k1 + 16 fg + n2 meets
+// bank (k1 + 16 fg + n2) mod 32: distinct over each half wave.  16 x 129 dwords fit the wave's eight P rows (2080).
+#define CTU_ADDTID16_P(E, BASE, OFF)                                                                                                 \
+    do {                                                                                                                             \
+        uint32_t keep_;                                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"                                                         \
+                     "ds_write_addtid_b32 %1 offset:%c18\n\tds_write_addtid_b32 %2 offset:516+%c18\n\tds_write_addtid_b32 %3 offset:1032+%c18\n\t"  \
+                     "ds_write_addtid_b32 %4 offset:1548+%c18\n\tds_write_addtid_b32 %5 offset:2064+%c18\n\tds_write_addtid_b32 %6 offset:2580+%c18\n\t" \
+                     "ds_write_addtid_b32 %7 offset:3096+%c18\n\tds_write_addtid_b32 %8 offset:3612+%c18\n\tds_write_addtid_b32 %9 offset:4128+%c18\n\t" \
+                     "ds_write_addtid_b32 %10 offset:4644+%c18\n\tds_write_addtid_b32 %11 offset:5160+%c18\n\tds_write_addtid_b32 %12 offset:5676+%c18\n\t" \
+                     "ds_write_addtid_b32 %13 offset:6192+%c18\n\tds_write_addtid_b32 %14 offset:6708+%c18\n\tds_write_addtid_b32 %15 offset:7224+%c18\n\t" \
+                     "ds_write_addtid_b32 %16 offset:7740+%c18\n\ts_mov_b32 m0, %0"                                                        \
+                     : "=&s"(keep_)                                                                                                  \
+                     : "v"(E(0)), "v"(E(1)), "v"(E(2)), "v"(E(3)), "v"(E(4)), "v"(E(5)), "v"(E(6)), "v"(E(7)), "v"(E(8)), "v"(E(9)),   \
+                       "v"(E(10)), "v"(E(11)), "v"(E(12)), "v"(E(13)), "v"(E(14)), "v"(E(15)), "s"(BASE), "n"(OFF)                    \
+                     : "memory");                                                                                                    \
+    } while (0)
+
+// The sixteen (pass A, pass B) pairs of one component back from that layout: ds_read2_b32 with offset0 = n2, offset1 = 64 + n2
+// fills a register pair with the two passes' values (the compiler's own pairing of ds_read_b32s goes by adjacent addresses,
+// which would pair n2 with n2 + 1 and cost a move per value).  Inline assembly is invisible to the compiler's wait-count
+// insertion: the statement waits for its own reads.
+#define CTU_READ2_PAIRS16(R, ADDR)                                                                                                   \
+    asm volatile("ds_read2_b32 %0, %16 offset0:0 offset1:64\n\tds_read2_b32 %1, %16 offset0:1 offset1:65\n\t"                        \
+                 "ds_read2_b32 %2, %16 offset0:2 offset1:66\n\tds_read2_b32 %3, %16 offset0:3 offset1:67\n\t"                        \
+                 "ds_read2_b32 %4, %16 offset0:4 offset1:68\n\tds_read2_b32 %5, %16 offset0:5 offset1:69\n\t"                        \
+                 "ds_read2_b32 %6, %16 offset0:6 offset1:70\n\tds_read2_b32 %7, %16 offset0:7 offset1:71\n\t"                        \
+                 "ds_read2_b32 %8, %16 offset0:8 offset1:72\n\tds_read2_b32 %9, %16 offset0:9 offset1:73\n\t"                        \
+                 "ds_read2_b32 %10, %16 offset0:10 offset1:74\n\tds_read2_b32 %11, %16 offset0:11 offset1:75\n\t"                    \
+                 "ds_read2_b32 %12, %16 offset0:12 offset1:76\n\tds_read2_b32 %13, %16 offset0:13 offset1:77\n\t"                    \
+                 "ds_read2_b32 %14, %16 offset0:14 offset1:78\n\tds_read2_b32 %15, %16 offset0:15 offset1:79\n\t"                    \
+                 "s_waitcnt lgkmcnt(0)"                                                                                              \
+                 : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]), "=&v"(R[5]), "=&v"(R[6]), "=&v"(R[7]), "=&v"(R[8]), \
+                   "=&v"(R[9]), "=&v"(R[10]), "=&v"(R[11]), "=&v"(R[12]), "=&v"(R[13]), "=&v"(R[14]), "=&v"(R[15])                       \
+                 : "v"(ADDR)                                                                                                         \
+                 : "memory")
 
 // Transpose of 16 x 16 complex values between "lane" and "register" inside each 16-lane group of a wave, through an LDS
 // scratch of 16 x 65 dwords (re, then im): element (k1, n2) of group fg sits at dword 65 k1 + 16 fg + n2 = 65 k1 + lane.
@@ -209,6 +291,14 @@ __device__ __forceinline__ void wave_transpose16_dual(float2 (&va)[16], float2 (
     for (int n2 = 0; n2 < 16; n2++) reb[n2] = rdb[n2];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#if defined(CTU_ABL) && (CTU_ABL & 4)  // diagnostic: no imaginary transpose (wrong results)
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) {
+        va[n2] = make_float2(rea[n2], va[n2].y);
+        vb[n2] = make_float2(reb[n2], vb[n2].y);
+    }
+    return;
+#endif
     CTU_ADDTID16(va, y, sa);
     CTU_ADDTID16(vb, y, sb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
