@@ -822,14 +822,19 @@ void build_tables(ctu_engine *e) {
     }
 }
 
-// One front-end launch.  The 160 KiB dynamic-LDS attribute is set once per engine (= per device) and instantiation.
+// Kernels whose dynamic LDS may pass the 64 KiB default: the 160 KiB attribute is set once per engine (= per device) and instantiation.
 template <class K>
-void launch_fe(ctu_engine *e, K kern, dim3 grid, hipStream_t s, const KParams &kp) {
+void allow_big_lds(ctu_engine *e, K kern) {
     const void *fp = reinterpret_cast<const void *>(kern);
     if (!e->attr_done.count(fp)) {
         HIP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e->attr_done.insert(fp);
     }
+}
+// One front-end launch.
+template <class K>
+void launch_fe(ctu_engine *e, K kern, dim3 grid, hipStream_t s, const KParams &kp) {
+    allow_big_lds(e, kern);
     hipLaunchKernelGGL(kern, grid, dim3(WG), e->lds_bytes, s, kp);
 }
 
@@ -1659,9 +1664,15 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             tp.inv_D = (unsigned)((1ull << 32) / (unsigned)tp.D) + 1u;
             const dim3 tg((unsigned)std::max<int64_t>(1, std::min<int64_t>((pl->total_frames + 255) / 256, (int64_t)e->n_cu * 8)));
             const size_t tshm = (size_t)256 * ((tp.stride | 1) * ((e->feat == FEAT_LPD || e->big) ? 8 : 4) + (tp.D | 1) * 4);
-            if (e->feat == FEAT_LPD || e->big) hipLaunchKernelGGL((lp_tail_kernel<double, 0>), tg, dim3(256), tshm, s, tp);
-            else if (kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) hipLaunchKernelGGL((lp_tail_kernel<float, 12>), tg, dim3(256), tshm, s, tp);
-            else hipLaunchKernelGGL((lp_tail_kernel<float, 0>), tg, dim3(256), tshm, s, tp);
+            // double lags at orders 20..23 pass 64 KiB (order 23 with -fea_E: 75 KiB)
+            if (e->feat == FEAT_LPD || e->big) {
+                if (tshm > 64 * 1024) allow_big_lds(e, &lp_tail_kernel<double, 0>);
+                hipLaunchKernelGGL((lp_tail_kernel<double, 0>), tg, dim3(256), tshm, s, tp);
+            } else if (kp.lporder == 12 && kp.ncep == 12 && !kp.lp_is_lpa) hipLaunchKernelGGL((lp_tail_kernel<float, 12>), tg, dim3(256), tshm, s, tp);
+            else {
+                if (tshm > 64 * 1024) allow_big_lds(e, &lp_tail_kernel<float, 0>);
+                hipLaunchKernelGGL((lp_tail_kernel<float, 0>), tg, dim3(256), tshm, s, tp);
+            }
             HIP_TRY(hipGetLastError());
         }
         if (e->do_vad) {
@@ -1754,8 +1765,14 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             // then the detector's recurrences, sixteen utterances per wave
             if (CTU_VF_A2C)
                 hipLaunchKernelGGL((vad_a2c_kernel<VF_NC>), dim3((unsigned)((pl->total_frames + 255) / 256)), dim3(256), 0, s, pl->vad_cf.p, (int64_t)pl->total_frames);
-            hipLaunchKernelGGL((vad_lanes_kernel<VF_NC>), dim3((pl->n_live + 15) / 16), dim3(64), 0, s, pl->vad_cf.p, pl->vf_order.p, pl->n_live,
-                               pl->d_row_off.p, d_vad, e->vp);
+#define LANES_LAUNCH(THR) hipLaunchKernelGGL((vad_lanes_kernel<VF_NC, THR>), dim3((pl->n_live + 15) / 16), dim3(64), 0, s, pl->vad_cf.p, pl->vf_order.p, pl->n_live, pl->d_row_off.p, d_vad, e->vp)
+            switch (e->vp.thr) {
+                case 0: LANES_LAUNCH(0); break;
+                case 1: LANES_LAUNCH(1); break;
+                case 2: LANES_LAUNCH(2); break;
+                default: LANES_LAUNCH(3); break;
+            }
+#undef LANES_LAUNCH
             HIP_TRY(hipGetLastError());
         }
         if (e->do_vad && !e->vf) {

@@ -100,6 +100,9 @@ struct KParams {
     int dbg;  // diagnostic ablation (CTU_DEBUG_MODE): 1 = phase 1 only, 2 = phase 2 only; 0 in production
 };
 
+#ifndef CTU_VF_A2C
+#define CTU_VF_A2C 1  // fused Burg-cepstral criterion: 1 = the front end stops at the lattice and vad_a2c_kernel finishes the cepstra (vad_fused.h); 0: the tail stays inside the front end (A/B)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;

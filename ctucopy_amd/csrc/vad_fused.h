@@ -353,9 +353,6 @@ __device__ __forceinline__ int cepdet_frame(CepDetRun &d, double cil, int lane, 
 // The coefficient recursion and a -> c of the fused Burg-cepstral criterion, one frame per lane (see RC_ONLY above): a row of the
 // scratch holds {alpha, k_1 .. k_{NC-1}} when the front end leaves it and the NC cepstra afterwards, which is what vad_lanes_kernel
 // reads.  The front end's sixteen lanes per frame spent 65 vector instructions per frame repeating this; here it is 4.
-#ifndef CTU_VF_A2C
-#define CTU_VF_A2C 1  // 0: the tail stays inside the front end (A/B)
-#endif
 template <int NC>
 __global__ __launch_bounds__(256) void vad_a2c_kernel(float *__restrict__ cf, int64_t total_frames) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -376,6 +373,11 @@ __global__ __launch_bounds__(256) void vad_a2c_kernel(float *__restrict__ cf, in
     vf_lattice_to_cepstrum<NC, float, true>(v[0], a, cc);
 #pragma unroll
     for (int i = 0; i < NC; i++) v[i] = cc[i];
+    // what the distance does not sum - coefficient 0 and the row's padding - leaves as zeros: vad_lanes_kernel needs no masks then
+    // (its background cepstrum of such an entry stays zero, and so does the entry's term)
+    v[0] = 0.f;
+#pragma unroll
+    for (int i = NC; i < VFC_STRIDE; i++) v[i] = 0.f;
 #pragma unroll
     for (int q = 0; q < VFC_STRIDE / 4; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }

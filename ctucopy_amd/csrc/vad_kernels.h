@@ -309,7 +309,8 @@ __device__ __forceinline__ void vad_flush(VadRun &r, const VadParams &vp, int T,
 // utterance; everything but the distance's summation order is vad_frame / vad_flush statement for statement.
 constexpr int VFC_STRIDE = 16;  // floats per frame in the cepstra scratch: the fused path's 14 coefficients, 64-byte rows
 
-template <int NCL>  // cepstral coefficients (<= 16)
+template <int NCL, int THR>  // cepstral coefficients (<= 16); threshold mode (vp.thr) at compile time: the launch lasts as long as its longest
+                              // utterance's chain of frames, one wave per SIMD - every instruction of a frame's step is on the critical path
 __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__ cf, const int *__restrict__ order, int n_live,
                                                         const int64_t *__restrict__ row_off, uint8_t *__restrict__ vad_out, VadParams vp) {
     static_assert(NCL <= 16, "four lanes x four coefficients");
@@ -362,24 +363,25 @@ __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int k = 4 * pq + i;
-                    const double dl = (k >= 1 && k < NCL) ? ci[i] - c0[i] : 0.0;  // c0 itself is not part of the distance
+                    // c0 itself is not part of the distance; vad_a2c_kernel stores zeros there and in the row's padding
+                    const double dl = (CTU_VF_A2C || (k >= 1 && k < NCL)) ? ci[i] - c0[i] : 0.0;
                     sum += dl * dl;
                 }
                 sum += dpp_mov<0xB1>(sum);  // quad_perm [1,0,3,2]
                 sum += dpp_mov<0x4E>(sum);  // quad_perm [2,3,0,1]
                 cri = 4.3429 * sqrt(2 * sum);
             }
-            if (t < T) {
+            {   // a quad beyond its utterance's end keeps stepping on zeros: its detector state is spent, only the filter and the stores below are guarded
                 int vad0;
-                if (vp.thr == 0) vad0 = cri >= vp.abs_thr;
-                else if (vp.thr == 1) {
+                if (THR == 0) vad0 = cri >= vp.abs_thr;
+                else if (THR == 1) {
                     if (t == 0 || (double)t < (double)vp.perc_init) crimin = crimax = cri;
                     else {
                         crimin = cri < crimin ? cri : crimin;
                         crimax = cri > crimax ? cri : crimax;
                     }
                     vad0 = cri >= crimin + (vp.perc_thr / 100.0) * (crimax - crimin);
-                } else if (vp.thr == 2) {
+                } else if (THR == 2) {
                     if (t == 0) {
                         crimean = cri;
                         crimean2 = cri * cri;
@@ -415,10 +417,12 @@ __global__ __launch_bounds__(64) void vad_lanes_kernel(const float *__restrict__
 #pragma unroll
                     for (int i = 0; i < 4; i++) c0[i] = vp.cep_p * c0[i] + (1.0 - vp.cep_p) * ci[i];
                 }
-                push(vad0);
-                if (t >= h) {
-                    if (pq == 0) out[nout] = (2 * nsum >= order_f) ? '1' : '0';
-                    nout++;
+                if (t < T) {
+                    push(vad0);
+                    if (t >= h) {
+                        if (pq == 0) out[nout] = (2 * nsum >= order_f) ? '1' : '0';
+                        nout++;
+                    }
                 }
             }
         }
