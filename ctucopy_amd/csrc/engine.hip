@@ -211,7 +211,9 @@ std::string unsupported_reason(const ctu::Design &d) {
         }
         if (o.nr_mode != "none" && o.nr_mode != "exten") return "nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221)";
         if (o.rasta) return "-nr_rasta";
-        if (o.do_vad()) return "VAD together with signal output";
+        // BATCH only constructs its VAD on the feature paths (init_out, src/io/batch.cc:70-76); with signal output save_frame() calls
+        // through the never-assigned pointer (batch.cc:230-241): the reference crashes, there is nothing to reproduce
+        if (o.do_vad()) return "VAD together with signal output (the reference dereferences a VAD it never constructs there, src/io/batch.cc:62-66,230-241)";
         if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
         if (d.window % 2) return "odd window length with signal output";
         if (d.window < 32) return "window shorter than 32 samples";
@@ -226,6 +228,10 @@ std::string unsupported_reason(const ctu::Design &d) {
         if (o.do_vad() && !(o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea")) return "-remove_dc1 together with a VAD criterion on the spectrum";
     }
     if (o.nr_mode != "none" && o.nr_mode != "exten") {
+        // -vad_apply_mode silence zeroes in->_Xsabs behind a non-speech frame (src/vad/vad.cc:727-736).  The features of the frame are
+        // out by then and the next get_frame() rewrites the vector, so on every other chain the mode changes nothing - but these
+        // modes seed the next file's noise estimate from that very vector (src/nr/nr.cc:212-221)
+        if (o.vad_apply_mode == "silence") return "-vad_apply_mode silence together with hwss / fwss / 2fwss (it zeroes the vector the next file's noise estimate starts from)";
         if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., plain chain)";
     }
     if (o.nr_when_afterFB) {

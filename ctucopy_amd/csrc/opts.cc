@@ -370,7 +370,7 @@ std::string Opts::usage() const {
            "  NR:       -nr_mode none|exten  -nr_p <p>  -nr_a <a>\n"
            "  features: -fea_kind spec|logspec|dctc|lpa|lpc|trapdct,<len>,<ndct>  -fea_lporder <n>\n"
            "            -fea_ncepcoefs <n>  -fea_c0|-fea_E|-fea_rawenergy on|off  -fea_lifter <L>\n"
-           "  VAD:      -vad burg  -vad_out_mode none|vad  -vad_apply_mode none|drop  -vad_cri_mode energy|cepdist ...\n"
+           "  VAD:      -vad burg  -vad_out_mode none|vad  -vad_apply_mode none|silence|drop  -vad_cri_mode energy|cepdist ...\n"
            "  presets:  -preset mfcc|plpc   (order matters: later options override the preset)\n"
            "  misc:     -v -quiet -info -h --gpus <n>\n";
 }

@@ -757,6 +757,9 @@ static int design_all(ctuo_t *c) {
         if (!c->vad_from_file && o->nr_when_afterFB) { set_err(c, "NR: Cannot use Burg detector after filter bank!"); return -1; } /* nr.cc:194-195 */
         if (c->vad_from_file && o->nr_when_afterFB) { set_err(c, "oracle: hwss/fwss/2fwss after the filter bank are not restated"); return -1; }
         if (c->signal_out || o->rasta) { set_err(c, "oracle: hwss/fwss/2fwss are restated on the feature path only"); return -1; }
+        /* VAD::silence_frame (vad.cc:727-736) zeroes in->_Xsabs behind a non-speech frame: invisible elsewhere (the frame's features are
+         * out, the next get_frame() rewrites the vector), but these modes seed the next file from that vector (nr.cc:212-221) */
+        if (!strcmp(o->vad_apply_mode, "silence")) { set_err(c, "oracle: -vad_apply_mode silence together with hwss/fwss/2fwss is not restated"); return -1; }
     }
     if (o->stat_cmvn || o->apply_cmvn) {
         set_err(c, "oracle: CMVN post-processing is outside the restated path");
@@ -787,7 +790,9 @@ static int design_all(ctuo_t *c) {
         for (int j = 0; j < o->window; j++) c->W[j] = 0.54 - (1 - 0.54) * cos(2 * pi * j / (o->window - 1.));
     }
     if (c->signal_out) { /* row N3: IN -> NR -> sigOUT; no FB, no FEA (batch.cc:62-65) */
-        if (strcmp(o->vad_apply_mode, "none") || strcmp(o->vad_out_mode, "none")) { set_err(c, "oracle: VAD together with signal output is not restated"); return -1; }
+        /* BATCH constructs its VAD in init_out() only (batch.cc:70-76), which the signal path never reaches (batch.cc:62-66): save_frame()
+         * then calls through an unassigned pointer (batch.cc:230-241) - the reference crashes, nothing to restate */
+        if (strcmp(o->vad_apply_mode, "none") || strcmp(o->vad_out_mode, "none")) { set_err(c, "oracle: VAD together with signal output crashes in the reference (batch.cc:62-66,230-241)"); return -1; }
         r2hc_plan(c, o->wfft);
         /* OLA correction, out.cc:355-377: the largest sum of overlapping Hamming windows over all phases of the shift */
         double pi = 2. * asin(1.), min = 999.;

@@ -613,6 +613,23 @@ def test_random_configurations_match_the_oracle(Engine, seed, fs):
     assert ran >= 20, (ran, refused)
 
 
+def test_apply_mode_silence(Engine):
+    # -vad_apply_mode silence: the rows and decisions of `none` on the feature path (tests/test_oracle_vad_chain.py says why); refused
+    # with the *ss modes and - like every VAD option - with signal output, where the reference has no VAD object to call
+    from ctucopy_amd import CtuError
+    from tests.util import C4
+    utts = [synth_utt(79, 16000, fs=8000), sig("CS3")[:20000]]
+    for extra in ([], ["-fea_delta", "d_a"]):
+        rn, vn = Engine(C4 + extra + ["-vad_apply_mode", "none"]).extract(utts, want_vad=True)
+        rs, vs = Engine(C4 + extra + ["-vad_apply_mode", "silence"]).extract(utts, want_vad=True)
+        for a, b, c, d in zip(rn, rs, vn, vs):
+            assert np.array_equal(a, b) and np.array_equal(c, d)
+    with pytest.raises(CtuError, match="silence"):
+        Engine(C2 + "-nr_mode fwss -vad burg -vad_out_mode vad -vad_apply_mode silence".split())
+    with pytest.raises(CtuError, match="never constructs"):
+        Engine("-fs 16000 -format_in raw -format_out raw -preset exten -vad_out_mode vad".split())
+
+
 def test_fuzz_found_configurations_at_the_noise_floor(Engine):
     """The two configurations of tools/probes/fuzz_configs.py (25 further seeds, profiles/r03_fuzz_configs.txt) that leave the 1e-4
     element-wise bound although they belong to the well-conditioned class, held to the bound they meet: 2e-4 element-wise and 1e-4 of

@@ -40,3 +40,19 @@ def test_cms_leaves_the_spectral_criteria_alone():
     assert np.array_equal(v2, v1)
     keep = v1 == ord("1")
     assert r2.shape[0] == int(keep.sum())
+
+
+def test_apply_mode_silence_changes_nothing_on_the_feature_path():
+    # VAD::silence_frame (src/vad/vad.cc:727-736) zeroes in->_Xsabs behind a non-speech frame - after the frame's features left and
+    # before get_frame() rewrites the whole vector: rows and decisions are those of `none`; with the *ss modes (which seed the next
+    # file from that vector, src/nr/nr.cc:212-221) the oracle refuses; with signal output the reference has no VAD object at all
+    from oracle.oracle import OracleError
+    from tests.util import C4
+    u = synth_utt(78, 16000, fs=8000)
+    rows_n, vad_n = Oracle(C4 + ["-vad_apply_mode", "none"]).process(u, want_vad=True)
+    rows_s, vad_s = Oracle(C4 + ["-vad_apply_mode", "silence"]).process(u, want_vad=True)
+    assert np.array_equal(rows_n, rows_s) and np.array_equal(vad_n, vad_s) and 0 < (vad_s == ord("1")).sum() < vad_s.size
+    with pytest.raises(OracleError, match="silence"):
+        Oracle(C2 + "-nr_mode fwss -vad burg -vad_out_mode vad -vad_apply_mode silence".split())
+    with pytest.raises(OracleError, match="crashes in the reference"):
+        Oracle("-fs 16000 -format_in raw -format_out raw -preset exten -vad_out_mode vad".split())

@@ -16,8 +16,9 @@ for B in bin/ctucopy_thre bin/ctucopy_addr; do
   echo "== $B"
   export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=1:protect_shadow_gap=0"
   setarch x86_64 -R $B -fs 16000 -format_in raw -format_out htk -preset mfcc -S $D/list.scp --batch-mib 1 --io-threads 8 --write-threads 3 > $D/log_$(basename $B) 2>&1; echo "rc $?"
-  grep -c "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $D/log
-  grep -A12 "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $D/log_$(basename $B) | grep "main.cc" | sort | uniq -c | head -20
+  L=$D/log_$(basename $B)
+  echo "reports (every frame of every report counts, not only main.cc's): $(grep -c "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $L)"
+  grep -A12 "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $L | grep "main.cc" | sort | uniq -c | head -20
   ls $D/o | wc -l
   mv $D/i/f030.raw $D/i/x; setarch x86_64 -R $B -fs 16000 -format_in raw -format_out htk -preset mfcc -S $D/list.scp --batch-mib 1 > $D/log2_$(basename $B) 2>&1; echo "rc $? (missing file)"; mv $D/i/x $D/i/f030.raw
   grep -c "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $D/log2_$(basename $B); grep -B2 -A14 'Direct leak' $D/log2_$(basename $B) | grep 'main.cc\|Direct leak' | head -12; tail -2 $D/log2_$(basename $B) | cut -c1-200
