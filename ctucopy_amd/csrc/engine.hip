@@ -197,6 +197,7 @@ namespace {
 void set_error(ctu_engine *e, const std::string &m) { e->err = m; }
 
 bool ss_eligible(const ctu::Design &d);
+int ss_mode_of(const ctu::Opts &o);
 
 // reasons a valid ctucopy configuration is outside the accelerated path
 std::string unsupported_reason(const ctu::Design &d) {
@@ -209,7 +210,8 @@ std::string unsupported_reason(const ctu::Design &d) {
             if (d.window / d.wshift > 8) return "-remove_dc1 with more than 8 frames over a sample (window / shift above 8)";
             if (o.fea_E && o.fea_rawenergy) return "-remove_dc1 together with -fea_rawenergy";
         }
-        if (o.nr_mode != "none" && o.nr_mode != "exten") return "nr_mode hwss/fwss/2fwss seed their noise estimate from the previous file (src/nr/nr.cc:212-221)";
+        if (o.nr_mode != "none" && o.nr_mode != "exten" && !ss_eligible(d))
+            return "hwss / fwss / 2fwss with signal output outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., DC removal on)";
         if (o.rasta) return "-nr_rasta";
         // BATCH only constructs its VAD on the feature paths (init_out, src/io/batch.cc:70-76); with signal output save_frame() calls
         // through the never-assigned pointer (batch.cc:230-241): the reference crashes, there is nothing to reproduce
@@ -351,8 +353,16 @@ bool md_eligible(const ctu::Design &d) { return (CTU_MD && plain_cepstral(d) && 
 #define CTU_SS_CACHE 1  // 0: every pass of the seed iteration runs the detector again (A/B)
 #endif
 int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode == "fwss" ? 2 : o.nr_mode == "2fwss" ? 3 : 0; }
+// the same modes ahead of sigOUT (-format_out raw|wave): the NR object works on in->_Xsabs - magnitudes, -fb_power is forced off there -
+// and the enhanced frames go back to the time domain inside the front end (frontend_kernel<..., SS, SY>)
+bool ss_signal_eligible(const ctu::Design &d) {
+    const ctu::Opts &o = d.o;
+    const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
+    return CTU_SY && d.signal_out && ss_mode_of(o) && det_ok && fused_frame_shape(d) && o.remove_dc && !o.remove_dc1 && !o.rasta && !o.do_vad();
+}
 bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
+    if (d.signal_out) return ss_signal_eligible(d);
     const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
     // -vad file=<f> (nr.cc:205-209, 297-302): the decisions come from a byte stream instead of the detector; same kernel, same frame shapes
     const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
@@ -777,6 +787,19 @@ void build_tables(ctu_engine *e) {
         e->feat = FEAT_BANDS;
         e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;
         e->sy = CTU_SY;
+        e->ss = ss_eligible(d) ? ss_mode_of(d.o) : 0;
+        e->ss_file = e->ss && d.o.vadmode == "file";
+        if (e->ss) {  // the detector's Hann window is the only table (as build_phase2 lays it out for the feature path)
+            std::vector<float> ft;
+            const double m = 2 * 3.141592653 / d.window;
+            for (int i = 0; i < 16 * (d.wfft == 512 ? VF0_SPL : VF_SPL); i++) ft.push_back(i < d.window ? (float)(0.5 * (1 - std::cos(m * i))) : 0.f);
+            e->han_off = 0;
+            e->tab_floats = (int)ft.size();
+            ft.push_back(0.f);  // (where the lifter sits on the feature path)
+            e->lift_off = e->tab_floats;
+            e->ftab.upload(ft);
+            e->lds_bytes = ((size_t)TILE * PSTRIDE + e->tab_floats + LTW_FLOATS + (!e->mode ? NWAVE * VF0_STAGE : 0)) * sizeof(float);
+        }
         return;
     }
     Phase2Tables t;
@@ -879,6 +902,10 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     if (e->sy && kp.skip_phase2) {
         if (kp.remove_dc1) {
             if constexpr (NZ == 16) launch_fe(e, &frontend_kernel<16, FEAT_BANDS, MODE, false, 16, GEN_DC1, 0, false, false, false, true>, grid, s, kp);
+        }
+        else if (e->ss) {
+            if constexpr (MODE == 1 || NZ == 13) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, true, true>, grid, s, kp);
+            else throw std::runtime_error("internal: SS engine without an SS instantiation");
         }
         else launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, false, true>, grid, s, kp);
     }

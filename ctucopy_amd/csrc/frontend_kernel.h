@@ -89,9 +89,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
     constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
     static_assert(!MD || ((FEAT == FEAT_DCTC || FEAT == FEAT_LP) && NC == 16), "MD: DCT / cosine-iDFT tail with 16 coefficient rows");
     static_assert(!VF || !VX, "VF: no spectrum export");
-    static_assert(!SS || (!VX && !VF && GEN == GEN_PLAIN), "SS: plain chain");
+    static_assert(!SS || (!VX && !VF && (GEN == GEN_PLAIN || (SY && GEN == GEN_FULL))), "SS: plain chain, or signal output (magnitude spectra: run-time flags)");
     static_assert(!((VF || SS) && MODE == 0) || NZ == 13, "VF / SS in the 512-point mode: 400-sample windows (16 lanes x 25 samples)");
-    static_assert(!SY || (!VX && !VF && !SS && (GEN == GEN_FULL || GEN == GEN_DC1)), "SY: run-time flags, no export");
+    static_assert(!SY || (!VX && !VF && (GEN == GEN_FULL || GEN == GEN_DC1)), "SY: run-time flags, no export");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
     const bool o_fb_inld = FULL ? p.fb_inld != 0 : GEN == GEN_INLD, o_nr_exten = FULL ? p.nr_exten != 0 : GEN == GEN_EXTEN;
     const bool o_fb_power = FULL ? p.fb_power != 0 : true, o_remove_dc = FULL ? p.remove_dc != 0 : true;
@@ -601,6 +601,10 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     if (l16 == 0) {
                         pa[128] = v[8].x * v[8].x;
                         pb[128] = v[8].y * v[8].y;
+                        if constexpr (SS && SY) {  // X_A[128] = Re Z[128], X_B[128] = Im Z[128]: their signs (out.cc:419, see the SS block)
+                            pa[129] = v[8].x;
+                            pb[129] = v[8].y;
+                        }
                         if (o_remove_dc) pa[0] = pb[0] = 1e-10f;
                         if (VX && p.vad_export == 1) {
                             if (fa < nvalid) p.xri[(rbase + fa) * 129 + 128] = make_float2(v[8].x, 0.f);
@@ -633,6 +637,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                         const int k = l16 + 16 * k2;
                         prow[k] = pk;
                         prow[256 - k] = pm;
+                        if constexpr (SS && SY) {  // X[256] = conj(v) / 2 at k = 0: its real part's sign (out.cc:419, see the SS block)
+                            if (k2 == 0 && l16 == 0) prow[257] = vr;
+                        }
                         if (VX && p.vad_export == 1 && f < nvalid) {  // X[k] = u/2, X[256-k] = conj(v)/2
                             float2 *xo = p.xri + (rbase + f) * 257;
                             xo[k] = make_float2(0.5f * ur, 0.5f * ui);
@@ -653,7 +660,8 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         };
-        constexpr bool SY_HALVES = SY && MODE == 0;  // pass, NR and synthesis per half step: one transform output live at a time
+        constexpr bool SY_HALVES = SY && MODE == 0 && !SS;  // pass, NR and synthesis per half step: one transform output live at a time
+                                                            // (with the *ss modes the detector needs the whole step first: both stay)
         if constexpr (!SY_HALVES) phase1(3);
         // The step's eight time-domain frames rebuilt from the P rows (magnitudes) and vz (directions), then the Burg
         // cepstra of each (vad_fused.h).  Uses up the wave's P rows.  out[x]: lane 16 fg + i holds coefficient i of frame
@@ -750,9 +758,25 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             STAMP(12);  // VF / SS: frames re-laid, Burg lattice, cepstra
         };
 
+        // magnitude instead of power (src/io/in.cc:415-417), rows [r0, r1); off the default path
+        auto to_magnitude = [&](int r0, int r1) {
+            if (!o_fb_power && r1 > r0) {
+                for (int e = lane + r0 * p.K; e < r1 * p.K; e += 64) {
+                    const int f = e / p.K, k = e - f * p.K;
+                    float *q_ = Pw + f * PSTRIDE + k;
+                    *q_ = sqrtf(*q_);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+
         // ================= hwss / fwss / 2fwss (src/nr/nr.cc:181-442) =================
         if constexpr (SS) {
             if (nv > 0) {
+                // signal output: the NR works on magnitudes (-fb_power is forced off, src/io/opts.cc:285-288); all eight rows - a duplicate
+                // frame shares a complex transform with a real one and the synthesis reads both
+                if constexpr (SY) to_magnitude(0, (MODE == 1 || nv > 4) ? 8 : 4);
                 const bool two = p.ss_mode == 3;
                 const int utt = as_const(p.tile_utt)[tile];
                 if (rec.t0 == 0 && slot0 == 0) {  // new_file (nr.cc:212-221, 402-409): seed from the previous file's last vector
@@ -795,6 +819,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 if (lane < nv) p.ss_vbits[rbase + slot0 + lane] = (unsigned char)((vbits >> lane) & 1u);
                 // (3) the spectra again, then the subtraction proper, frames in order, lane = bin
                 phase1(3);
+                if constexpr (SY) to_magnitude(0, (MODE == 1 || nv > 4) ? 8 : 4);
                 }
                 const float pp = p.nr_p, qq = 1.0f - p.nr_p;
                 for (int f = 0; f < nv; f++) {
@@ -819,7 +844,13 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                                 X = ss_root(X, p.nr_a);
                             }
                             row[64 * j] = X;
-                            if (t == rec.T - 1) p.ss_last[(int64_t)utt * p.K + lane + 64 * j] = X;
+                            if (t == rec.T - 1) {
+                                // what the next file's noise estimate starts from (nr.cc:212-221).  With signal output sigOUT has flipped the
+                                // Nyquist entry's sign by then if that bin's phase was pi (src/io/out.cc:419): phase 1 left the bin's signed
+                                // real part behind the row's last bin
+                                if (SY && lane + 64 * j == p.K - 1 && row[64 * j + 1] < 0.f) X = -X;
+                                p.ss_last[(int64_t)utt * p.K + lane + 64 * j] = X;
+                            }
                         }
                     }
                 }
@@ -829,18 +860,6 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         }
 
 
-        // magnitude instead of power (src/io/in.cc:415-417), rows [r0, r1); off the default path
-        auto to_magnitude = [&](int r0, int r1) {
-            if (!o_fb_power && r1 > r0) {
-                for (int e = lane + r0 * p.K; e < r1 * p.K; e += 64) {
-                    const int f = e / p.K, k = e - f * p.K;
-                    float *q_ = Pw + f * PSTRIDE + k;
-                    *q_ = sqrtf(*q_);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
 
         // ================= extended spectral subtraction (src/nr/nr.cc:86-140) =================
         // Sequential in t, independent across bins: lane = bin (bin = lane + 64 j), the step's frames in order, the
@@ -935,7 +954,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             __builtin_amdgcn_wave_barrier();
         }
         };
-        if constexpr (!SY_HALVES) {
+        if constexpr (!SY_HALVES && !SS) {
             to_magnitude(0, SY ? 8 : nv);  // SY: all rows - a duplicate frame shares a complex transform with a real one
             apply_exten(0, nv);
         }
@@ -979,14 +998,18 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                             if (2 * (l16 + 16 * m) < p.window && fr < nvalid) y[16 * m] = vn[m];
                     };
                     const int n0 = nv < 4 ? nv : 4;
-                    phase1(1);
-                    to_magnitude(0, 4);
-                    apply_exten(0, n0);
+                    if constexpr (!SS) {
+                        phase1(1);
+                        to_magnitude(0, 4);
+                        apply_exten(0, n0);
+                    }
                     synth(vz, std::integral_constant<int, 0>{});
                     if (nv > 4) {
-                        phase1(2);
-                        to_magnitude(4, 8);
-                        apply_exten(4, nv);
+                        if constexpr (!SS) {
+                            phase1(2);
+                            to_magnitude(4, 8);
+                            apply_exten(4, nv);
+                        }
                         synth(vz1, std::integral_constant<int, 1>{});
                     }
                 }

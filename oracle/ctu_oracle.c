@@ -756,7 +756,7 @@ static int design_all(ctuo_t *c) {
         } else if (strcmp(o->vadmode, "burg")) { set_err(c, "NR: Unknown VAD mode!"); return -1; } /* nr.cc:276 */
         if (!c->vad_from_file && o->nr_when_afterFB) { set_err(c, "NR: Cannot use Burg detector after filter bank!"); return -1; } /* nr.cc:194-195 */
         if (c->vad_from_file && o->nr_when_afterFB) { set_err(c, "oracle: hwss/fwss/2fwss after the filter bank are not restated"); return -1; }
-        if (c->signal_out || o->rasta) { set_err(c, "oracle: hwss/fwss/2fwss are restated on the feature path only"); return -1; }
+        if (o->rasta) { set_err(c, "oracle: -nr_rasta is not restated"); return -1; }
         /* VAD::silence_frame (vad.cc:727-736) zeroes in->_Xsabs behind a non-speech frame: invisible elsewhere (the frame's features are
          * out, the next get_frame() rewrites the vector), but these modes seed the next file from that vector (nr.cc:212-221) */
         if (!strcmp(o->vad_apply_mode, "silence")) { set_err(c, "oracle: -vad_apply_mode silence together with hwss/fwss/2fwss is not restated"); return -1; }
@@ -1476,6 +1476,47 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         }                                                                                                                      \
     } while (0)
 
+/* hwssNR / fwssNR / dfwssNR::process_frame (nr.cc:223-261, 331-369, 418-442) on the vector XVEC (K values); `break`s out of the frame loop on a failed VAD stream */ \
+#define SS_STEP(XVEC) { \
+ /* hwssNR / fwssNR / dfwssNR::process_frame, nr.cc:223-261, 331-369, 418-442 */ \
+                    const double aexp = o->nr_a, bsub = o->nr_b, p = o->nr_p; \
+                    double *X = (XVEC); \
+                    if (c->ss_mode == 1) ss_ninit--;                       /* hwss counts down first (nr.cc:225) */ \
+                    if (c->ss_mode != 3) {                                 /* dynamic expansion */ \
+                        if (aexp == 2.0) for (int i = 0; i < K; i++) X[i] *= X[i]; \
+                        else if (aexp != 1.0) for (int i = 0; i < K; i++) X[i] = pow(X[i], aexp); \
+                    } \
+                    int vad; \
+                    if (c->vad_from_file) { \
+                        /* nr.cc:297-302: `char vad = fgetc(fvad); if (vad != EOF) return bool(vad); else throw ...` - every byte but NUL \
+                         * is speech (an ASCII '0' too), and a byte 0xFF compares equal to EOF in the (signed) char and ends the run */ \
+                        const int ch = c->vad_pos < c->vad_len ? (int)c->vad_stream[c->vad_pos++] : EOF; \
+                        const char vc = (char)ch; \
+                        if (vc == EOF) { set_err(c, "NR: Unexpected end of VAD file!"); fail = 1; break; } \
+                        vad = vc != 0; \
+                    } else { \
+                        /* vad_get_frame, nr.cc:278-295: back to the time domain with the original phase, first `window` samples */ \
+                        for (int i = 0; i < K; i++) { ss_re[i] = X[i] * cos(Xph[i]); ss_im[i] = (i == 0 || i == K - 1) ? 0.0 : X[i] * sin(Xph[i]); } \
+                        hc2r(ss_re, ss_im, wfft, ss_t, ss_w1, ss_w2); \
+                        vad = ctuo_cepdet_process(ss_det, ss_t); \
+                    } \
+                    if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) Navg[i] = p * Navg[i] + (1 - p) * X[i]; \
+                    if (c->ss_mode == 3) { \
+                        for (int i = 0; i < K; i++) { X[i] -= Navg[i]; if (X[i] < 0.) X[i] = -X[i]; } \
+                        if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) ss_nr[i] = p * ss_nr[i] + (1 - p) * X[i]; \
+                        for (int i = 0; i < K; i++) { X[i] -= ss_nr[i]; if (X[i] < 0.) X[i] = -X[i]; } \
+                    } else { \
+                        for (int i = 0; i < K; i++) { \
+                            X[i] -= bsub * Navg[i]; \
+                            if (X[i] < 0.) X[i] = c->ss_mode == 1 ? 0. : -X[i]; \
+                        } \
+                        if (aexp == 2.) for (int i = 0; i < K; i++) X[i] = sqrt(X[i]); \
+                        else if (aexp != 1.) for (int i = 0; i < K; i++) X[i] = pow(X[i], 1.0 / aexp); \
+                    } \
+                    if (c->ss_mode != 1) ss_ninit--; \
+                    memcpy(c->ss_stale, X, sizeof(double) * K); \
+}
+
     for (long t = 0; t < T && !fail; t++) {
         const long s = t * (long)wshift;
         /* ---- rawIN::get_frame, in.cc:305-419 */
@@ -1537,6 +1578,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                     Xabs[i] -= N;
                 }
             }
+            if (c->ss_mode) SS_STEP(Xabs)   /* the same NR object on in->_Xsabs (batch.cc:62-66) */
             /* out.cc:405-434.  The ring slots that fall out of the window are cleared, the spectrum goes back to
              * Re/Im with the ORIGINAL phase and a 1/N factor (DC and Nyquist keep their magnitude as a positive real:
              * the sign flip at out.cc:419 comes after the value was stored), HC2R, overlap-add of the first `window`
@@ -1550,6 +1592,9 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                 sre[i] = ampl * cos(Xph[i]);
                 sim[i] = ampl * sin(Xph[i]);
             }
+            /* out.cc:419: `if(Xp[size-1]!=0) Xa[size-1]=-Xa[size-1];` - after its value went into the transform.  Nothing reads the vector
+             * again in this file, but hwss / fwss / 2fwss seed the NEXT file's noise estimate from it (nr.cc:212-221) */
+            if (c->ss_mode && Xph[K - 1] != 0) c->ss_stale[K - 1] = -c->ss_stale[K - 1];
             hc2r(sre, sim, wfft, ytime, sw1, sw2);
             for (int i = 0; i < window; i++) ola[(ola_start + i) % window] += ytime[i];
             for (int i = 0; i < wshift; i++) {
@@ -1588,44 +1633,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                         nrvec[i] -= N;
                     }
                 }
-                if (c->ss_mode) { /* hwssNR / fwssNR / dfwssNR::process_frame, nr.cc:223-261, 331-369, 418-442 */
-                    const double aexp = o->nr_a, bsub = o->nr_b, p = o->nr_p;
-                    double *X = nrvec;
-                    if (c->ss_mode == 1) ss_ninit--;                       /* hwss counts down first (nr.cc:225) */
-                    if (c->ss_mode != 3) {                                 /* dynamic expansion */
-                        if (aexp == 2.0) for (int i = 0; i < K; i++) X[i] *= X[i];
-                        else if (aexp != 1.0) for (int i = 0; i < K; i++) X[i] = pow(X[i], aexp);
-                    }
-                    int vad;
-                    if (c->vad_from_file) {
-                        /* nr.cc:297-302: `char vad = fgetc(fvad); if (vad != EOF) return bool(vad); else throw ...` - every byte but NUL
-                         * is speech (an ASCII '0' too), and a byte 0xFF compares equal to EOF in the (signed) char and ends the run */
-                        const int ch = c->vad_pos < c->vad_len ? (int)c->vad_stream[c->vad_pos++] : EOF;
-                        const char vc = (char)ch;
-                        if (vc == EOF) { set_err(c, "NR: Unexpected end of VAD file!"); fail = 1; break; }
-                        vad = vc != 0;
-                    } else {
-                        /* vad_get_frame, nr.cc:278-295: back to the time domain with the original phase, first `window` samples */
-                        for (int i = 0; i < K; i++) { ss_re[i] = X[i] * cos(Xph[i]); ss_im[i] = (i == 0 || i == K - 1) ? 0.0 : X[i] * sin(Xph[i]); }
-                        hc2r(ss_re, ss_im, wfft, ss_t, ss_w1, ss_w2);
-                        vad = ctuo_cepdet_process(ss_det, ss_t);
-                    }
-                    if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) Navg[i] = p * Navg[i] + (1 - p) * X[i];
-                    if (c->ss_mode == 3) {
-                        for (int i = 0; i < K; i++) { X[i] -= Navg[i]; if (X[i] < 0.) X[i] = -X[i]; }
-                        if (vad == 0 || ss_ninit > 0) for (int i = 0; i < K; i++) ss_nr[i] = p * ss_nr[i] + (1 - p) * X[i];
-                        for (int i = 0; i < K; i++) { X[i] -= ss_nr[i]; if (X[i] < 0.) X[i] = -X[i]; }
-                    } else {
-                        for (int i = 0; i < K; i++) {
-                            X[i] -= bsub * Navg[i];
-                            if (X[i] < 0.) X[i] = c->ss_mode == 1 ? 0. : -X[i];
-                        }
-                        if (aexp == 2.) for (int i = 0; i < K; i++) X[i] = sqrt(X[i]);
-                        else if (aexp != 1.) for (int i = 0; i < K; i++) X[i] = pow(X[i], 1.0 / aexp);
-                    }
-                    if (c->ss_mode != 1) ss_ninit--;
-                    memcpy(c->ss_stale, X, sizeof(double) * K);
-                }
+                if (c->ss_mode) SS_STEP(nrvec)
                 if (o->fea_E && !o->fea_rawenergy) { /* _NR::compute_E, nr.cc:36-45 */
                     double E = nrvec[0] * nrvec[0] / 2. + nrvec[nrsize - 1] * nrvec[nrsize - 1] / 2.;
                     for (int i = 1; i < nrsize - 1; i++) E += nrvec[i] * nrvec[i];

@@ -563,6 +563,50 @@ def test_enhancement_output(Engine, extra, max_lsb, mean_lsb):
         assert d.mean() <= mean_lsb, d.mean()
 
 
+@pytest.mark.parametrize("mode,fs,extra", [("fwss", 16000, []), ("fwss", 8000, []), ("hwss", 16000, ["-nr_a", "2"]), ("2fwss", 8000, []),
+                                           ("2fwss", 16000, ["-nr_p", "0.9"]), ("hwss", 8000, ["-nr_b", "0.8"])])
+def test_spectral_subtraction_with_signal_output(Engine, mode, fs, extra):
+    """-nr_mode hwss | fwss | 2fwss -format_out raw (src/nr/nr.cc:212-442 ahead of src/io/out.cc:405-434): the NR
+    works on magnitudes, the Burg cepstral detector decides, the frames go back through the inverse transform and the overlap-add.
+    A list of files: each starts its noise estimate from the vector the previous one left (with sigOUT's sign flip of the Nyquist
+    entry); the engine and the oracle walk it as one process.  Parity in LSBs as for the exten preset (2 LSB, mean below 0.3)."""
+    cfg = f"-fs {fs} -format_in raw -format_out raw -w 25 -s 12.5 -nr_mode {mode} -vad burg".split() + extra
+    step = 16000 // fs
+    utts = [sig("CS0")[::step][:20000 // step].copy(), synth_utt(91, 24000 // step, fs=fs), sig("CS3")[::step][6000 // step:30000 // step].copy(),
+            np.zeros(3 * fs // 160, np.int16), synth_utt(92, 17000 // step, fs=fs)]   # the fourth: no frame (0.1 x the stale vector for the fifth)
+    eng, orc = Engine(cfg), Oracle(cfg)
+    assert eng.dims.signal_out == 1 and eng.kernel_name().endswith("SS, SY>")
+    got = eng.enhance(utts)
+    for k, (u, g) in enumerate(zip(utts, got)):
+        ref = orc.enhance(u)
+        assert g.shape == ref.shape and g.dtype == np.int16, k
+        d = np.abs(g.astype(int) - ref.astype(int))
+        assert d.max() <= 2 and d.mean() <= 0.3, (k, d.max(), d.mean())
+    # a second run of the same engine goes on from the vector the first one left, like a longer list in the reference
+    again = eng.enhance(utts[:2])
+    for u, g in zip(utts[:2], again):
+        ref = orc.enhance(u)
+        d = np.abs(g.astype(int) - ref.astype(int))
+        assert g.shape == ref.shape and d.max() <= 2 and d.mean() <= 0.3
+
+
+@pytest.mark.parametrize("mode,fs", [("fwss", 16000), ("hwss", 8000)])
+def test_spectral_subtraction_with_signal_output_and_decisions_from_a_file(Engine, tmp_path, mode, fs):
+    cfg0 = f"-fs {fs} -format_in raw -format_out raw -w 25 -s 12.5 -nr_mode {mode} -nr_a 2".split()
+    utts = [synth_utt(93 + k, fs * 2 + 333 * k, fs=fs) for k in range(4)]
+    probe = Oracle(cfg0 + ["-vad", "burg"])
+    frames = [probe.num_frames(u.size) for u in utts]
+    stream = np.random.default_rng(21).choice(np.array([0, 0, 1, 9], np.uint8), sum(frames))
+    f = tmp_path / "vad.bin"
+    f.write_bytes(bytes(stream))
+    cfg = cfg0 + ["-vad", f"file={f}"]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    for u, g in zip(utts, eng.enhance(utts)):
+        ref = orc.enhance(u)
+        d = np.abs(g.astype(int) - ref.astype(int))
+        assert g.shape == ref.shape and d.max() <= 2 and d.mean() <= 0.3
+
+
 def test_enhancement_8khz_and_api_guards(Engine):
     from ctucopy_amd import CtuError
     cfg = "-fs 8000 -format_in raw -format_out raw -preset exten".split()  # 256-point transform, two frames per FFT

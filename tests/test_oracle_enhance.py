@@ -64,3 +64,86 @@ def test_exten_preset_attenuates_and_keeps_length():
     assert len(y) == o.num_frames(len(X)) * 256 + 256
     assert 0.2 < np.abs(y.astype(float)).mean() / np.abs(X.astype(float)).mean() < 0.9
     assert np.array_equal(y, o.enhance(X))  # NR state is per file
+
+
+def numpy_ss_sigout(files, window, wshift, wfft, mode, a, b, p, initsegs, stream):
+    """hwss (1) / fwss (2) / 2fwss (3) ahead of sigOUT with the decisions from a byte stream (src/nr/nr.cc:212-442, src/io/out.cc:405-434),
+    written with numpy's transforms: the noise seed runs from file to file through the spectrum vector the previous file left - with the
+    Nyquist entry's sign flipped by sigOUT when that bin's phase was pi (out.cc:419) - times 0.1 per new_file (nr.cc:217-220)."""
+    K = wfft // 2 + 1
+    j = np.arange(window)
+    ham = 0.54 - 0.46 * np.cos(2 * np.pi * j / (window - 1.0))
+    corr = max(sum(0.54 - 0.46 * np.cos(2 * np.pi * k / (window - 1.0)) for k in range(i, window, wshift)) for i in range(wshift))
+    stale = np.zeros(K)
+    pos = 0
+    outs = []
+    for x in files:
+        x = x.astype(np.float64)
+        T = (len(x) - (window - wshift)) // wshift
+        navg = stale.copy() if mode == 3 else stale ** a
+        stale = stale * 0.1
+        nr = np.zeros(K)
+        ninit = initsegs
+        out = np.zeros(T * wshift + window)
+        for t in range(T):
+            f = x[t * wshift:t * wshift + window] * ham
+            f = f - f.mean()
+            S = np.fft.rfft(f, wfft)
+            mag, ph = np.abs(S), np.angle(S)
+            mag[0] = np.sqrt(1e-10)
+            X = mag.copy()
+            if mode == 1:
+                ninit -= 1
+            if mode != 3:
+                X = X ** a
+            speech = stream[pos] != 0
+            pos += 1
+            upd = (not speech) or ninit > 0
+            if upd:
+                navg = p * navg + (1 - p) * X
+            if mode == 3:
+                X = np.abs(X - navg)
+                if upd:
+                    nr = p * nr + (1 - p) * X
+                X = np.abs(X - nr)
+            else:
+                X = X - b * navg
+                X = np.maximum(X, 0.0) if mode == 1 else np.abs(X)
+                X = X ** (1.0 / a)
+            if mode != 1:
+                ninit -= 1
+            stale = X.copy()
+            if S[-1].real < 0:
+                stale[-1] = -stale[-1]
+            Y = X * np.exp(1j * ph)
+            Y[0] = X[0]
+            Y[-1] = X[-1]
+            out[t * wshift:t * wshift + window] += np.fft.irfft(Y, wfft)[:window]
+        n = T * wshift + window - wshift
+        v = np.floor(out[:n] / corr)
+        outs.append(np.where(np.abs(v) > 32767, np.sign(v) * 32767, v).astype(np.int16))
+    return outs
+
+
+@pytest.mark.parametrize("mode,a", [("hwss", 1.0), ("fwss", 2.0), ("2fwss", 1.0), ("fwss", 1.0)])
+def test_spectral_subtraction_ahead_of_sigout_equals_numpy(tmp_path, mode, a):
+    files = [sig("CS0")[:20000], sig("CS3")[4000:30000], sig("CS0")[30000:52000]]
+    w, sft = 400, 200
+    frames = [(len(x) - (w - sft)) // sft for x in files]
+    stream = np.random.default_rng(12).choice(np.array([0, 0, 1, 5], np.uint8), sum(frames))
+    (tmp_path / "vad.bin").write_bytes(bytes(stream))
+    cfg = ("-fs 16000 -format_in raw -format_out raw -fea_kind none -fb_definition none -w 25 -s 12.5 -nr_mode %s -nr_a %g -nr_b 0.9 "
+           "-nr_initsegs 6" % (mode, a)).split() + ["-vad", "file=%s" % (tmp_path / "vad.bin")]
+    o = Oracle(cfg)
+    ref = numpy_ss_sigout(files, w, sft, 512, {"hwss": 1, "fwss": 2, "2fwss": 3}[mode], a, 0.9, 0.95, 6, stream)
+    for x, r in zip(files, ref):
+        y = o.enhance(x)
+        assert y.shape == r.shape
+        diff = np.abs(y.astype(int) - r.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+    # no subtraction (b = 0, a = 1): the plain resynthesis
+    plain = Oracle("-fs 16000 -format_in raw -format_out raw -fea_kind none -fb_definition none -w 25 -s 12.5 -nr_mode none".split()).enhance(files[0])
+    (tmp_path / "vad.bin").write_bytes(bytes(stream))
+    same = Oracle(("-fs 16000 -format_in raw -format_out raw -fea_kind none -fb_definition none -w 25 -s 12.5 -nr_mode fwss -nr_b 0").split()
+                  + ["-vad", "file=%s" % (tmp_path / "vad.bin")]).enhance(files[0])
+    assert np.array_equal(plain, same)

@@ -23,3 +23,4 @@ for B in bin/ctucopy_thre bin/ctucopy_addr; do
   mv $D/i/f030.raw $D/i/x; setarch x86_64 -R $B -fs 16000 -format_in raw -format_out htk -preset mfcc -S $D/list.scp --batch-mib 1 > $D/log2_$(basename $B) 2>&1; echo "rc $? (missing file)"; mv $D/i/x $D/i/f030.raw
   grep -c "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $D/log2_$(basename $B); grep -B2 -A14 'Direct leak' $D/log2_$(basename $B) | grep 'main.cc\|Direct leak' | head -12; tail -2 $D/log2_$(basename $B) | cut -c1-200
 done
+mkdir -p gpurun_out/cli_sanitize_logs && for f in $D/log_* $D/log2_*; do head -c 200000 $f > gpurun_out/cli_sanitize_logs/$(basename $f).txt; done
