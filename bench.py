@@ -359,8 +359,23 @@ def main():
             if pm.get("kernel") == kname:
                 roof["traffic"] = pm["hbm_bytes_per_frame"] * plan.total_frames
                 roof["traffic_source"] = pm.get("source")
-                roof["valu_frac"] = fps_kernel * pm["valu_instr_per_frame"] / VALU_PEAK_WAVE_INSTR_S
+                # issue slots: a packed v_pk_*_f32 counts as the 1.9 plain instructions it costs inside this kernel, the conversion /
+                # select / DPP forms as 1.65 (profiles/r04_frontend_cost_model.txt); nominal peaks at 2.4 GHz
+                slots = pm.get("valu_issue_slots_per_frame", pm["valu_instr_per_frame"])
+                roof["valu_frac"] = fps_kernel * slots / VALU_PEAK_WAVE_INSTR_S
                 roof["lds_frac"] = fps_kernel * pm["lds_cycles_per_frame"] / LDS_PEAK_CYCLES_S
+                # The ceilings at the clock the chip holds under this kernel (GRBM_GUI_ACTIVE / 8 / kernel time of the PMC passes): a
+                # 512-point fp32 transform per frame on the vector ALUs cannot come near the HBM roofline - 0.70 of it would need
+                # <= 55 issue slots per frame, the radix-16 butterflies alone are 84 - so the fraction of min(HBM, VALU) stands beside `frac`
+                clk = pm.get("clock_ghz")
+                if clk:
+                    valu_ceiling = 256 * 4 * clk * 1e9 / 2.0 / slots          # one wave-instruction per 2 cycles and SIMD
+                    hbm_ceiling = HBM_PEAK_GBS * 1e9 / bytes_per_frame
+                    roof["clock_ghz"] = clk
+                    roof["valu_ceiling_frames_s"] = valu_ceiling
+                    roof["lds_ceiling_frames_s"] = 256 * clk * 1e9 / pm["lds_cycles_per_frame"]
+                    roof["hbm_ceiling_frames_s"] = hbm_ceiling
+                    roof["frac_of_min_hbm_valu"] = fps_kernel / min(hbm_ceiling, valu_ceiling)
                 if "mfma_busy_cycles_per_frame" in pm:  # matrix-pipe cycles summed over SIMDs: 1024 pipes at 2.4 GHz
                     roof["mfma_frac"] = fps_kernel * pm["mfma_busy_cycles_per_frame"] / (256 * 4 * 2.4e9)
                 roof["limiter"] = pm.get("limiter")
