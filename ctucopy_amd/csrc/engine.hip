@@ -269,7 +269,9 @@ std::string unsupported_reason(const ctu::Design &d) {
     }
     if (o.fea_E && d.kind == ctu::FeaKind::TrapDct) return "-fea_E with trapdct (the energy lags the features by 50 frames in the reference)";
     if (o.do_vad()) {
-        if (d.kind == ctu::FeaKind::TrapDct) return "VAD together with trapdct";
+        // trapdct delays the writer by half a context (src/fea/fea_trap.cc:53-127): the detector runs when a vector comes out, on the
+        // newest input frame's criterion - the delta chains' mechanism (vp.delay); the `fea` criterion would read 368-entry vectors
+        if (d.kind == ctu::FeaKind::TrapDct && o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode != "lpc") return "the `fea` VAD criterion on TRAP vectors";
         if (o.vad_cri_mode != "energy" && o.vad_cri_mode != "cepdist") return "";  // rejected with the reference's text at create
         if (o.vad_cri_mode == "cepdist") {
             if (o.vad_cepdist_mode == "in") return "-vad_cepdist_mode in (HTK feature input)";
@@ -1109,6 +1111,7 @@ int ctu_engine_create(int argc, const char *const *argv, int device, ctu_engine 
             vp.D = d.D; vp.ncep = o.fea_ncepcoefs; vp.c0_slot = d.post_stack ? -2 : (d.row_slot.empty() ? -1 : d.row_slot[0]);  // -2: stacked rows keep the internal order (c0 first)
             vp.delay = 0;
             for (int j = 0; j < d.post_order; j++) vp.delay += d.post_w[j];
+            if (d.kind == ctu::FeaKind::TrapDct) vp.delay = (o.fea_trapdct_traplen - 1) / 2;
             vp.e_slot = o.fea_E ? (d.post_order > 0 ? d.D - 1 : d.e_slot) : -1;
             vp.e_delay = (o.vad_filter_order - 1) / 2;
         }

@@ -1432,7 +1432,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
     long nrows = 0, nvad = 0;
     int fail = 0;
 
-    if (is_post && do_vad) {
+    if ((is_post || is_trap) && do_vad) {
         en_t = calloc((size_t)(T > 0 ? T : 1), sizeof(double));
         if (vs.csize && !strcmp(o->vad_cepdist_mode, "lpc")) ci_t = calloc((size_t)(T > 0 ? T : 1) * vs.csize, sizeof(double));
     }
@@ -1711,13 +1711,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         else if (!strcmp(kind, "dctc")) E_out = o->nr_when_afterFB ? E_in : E_nr;
         else E_out = E_fea;
 
-        if (is_trap) { /* log-mel kept; TRAP computed after the loop (edge replication, fea_trap.cc:53-127) */
-            memcpy(trapbuf + (size_t)t * B, fvec, sizeof(double) * B);
-            trapE[t] = E_out;
-            continue;
-        }
-
-        if (do_vad && !is_trap) {
+        if (do_vad) {
             /* criterion inputs of this input frame: VADcri_energy (vad.cc:96-107) / VADcri_cepdist lpc (vad.cc:220-276) */
             if (!strcmp(o->vad_cri_mode, "energy")) {
                 double en = 0.0;
@@ -1731,6 +1725,20 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
                     ctuo_burg_cepstrum(tsig, window, vs.csize, NULL, vs.ci, NULL);
                 } else if (strcmp(o->vad_cepdist_mode, "fea")) { set_err(c, "VADcri_cepdist: vad_cepdist_mode=in and in->_fvec is not available!"); fail = 1; break; }
             } else { set_err(c, "VAD: unknown vad_cri_mode!"); fail = 1; break; }
+        }
+        if (is_trap) { /* log-mel kept; TRAP computed after the loop (edge replication, fea_trap.cc:53-127) */
+            memcpy(trapbuf + (size_t)t * B, fvec, sizeof(double) * B);
+            trapE[t] = E_out;
+            if (do_vad) { /* as behind a delta chain: the detector runs when a vector comes out, on the newest input frame's criterion */
+                if (!strcmp(o->vad_cri_mode, "cepdist") && !strcmp(o->vad_cepdist_mode, "fea")) {
+                    set_err(c, "oracle: the `fea` VAD criterion on TRAP vectors is not restated");
+                    fail = 1;
+                    break;
+                }
+                en_t[t] = cur_en;
+                if (ci_t) memcpy(ci_t + (size_t)t * vs.csize, vs.ci, sizeof(double) * vs.csize);
+            }
+            continue;
         }
         if (is_post) { /* deltaFEA chain replayed after the loop (it only consumes fvec and E) */
             memcpy(postbuf + (size_t)t * c->nfea, fvec, sizeof(double) * c->nfea);
@@ -1780,6 +1788,16 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
             /* E is read through a pointer at save time: it belongs to the newest frame
              * fed in, i.e. frame min(t+half, T-1) (batch.cc:116, fea_trap.cc:76-79). */
             long te = t + half; if (te > T - 1) te = T - 1;
+            if (do_vad) {
+                /* trapdctFEA::process_frame is false for the first `half` frames and flush_frame delivers the last `half` vectors
+                 * (fea_trap.cc:53-127), so BATCH::save_frame's call t (batch.cc:230-241) finds input frame min(t + half, T - 1) in
+                 * in->_Xsabs: the criterion the detector reads is that frame's */
+                cur_en = en_t[te];
+                if (ci_t) memcpy(vs.ci, ci_t + (size_t)te * vs.csize, sizeof(double) * vs.csize);
+                VAD_CALL(t, fvec, trapE[te]);
+                E_last = trapE[te];
+                continue;
+            }
             emit_row(c, fvec, trapE[te], rows + (size_t)nrows * c->D);
             nrows++;
         }
@@ -1847,7 +1865,7 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         E_last = postE[T - 1];
     }
 
-    if (!fail && do_vad && !is_trap) { /* BATCH::flush_vad, batch.cc:243-249; medianFilter::flush_frame, vad.h:156-175 */
+    if (!fail && do_vad) { /* BATCH::flush_vad, batch.cc:243-249; medianFilter::flush_frame, vad.h:156-175 */
         /* `while (vad->flush_frame())` runs on the filter's `ready` (vad.cc:742-745), which only a push that found the history
          * full sets (vad.h:126-136): a file with no more frames than the filter delays - (order-1)/2 - never gets there, the loop
          * does not start, and neither a row nor a decision is written for it (pinned by tests/test_oracle_median_ref.py) */
@@ -1876,7 +1894,6 @@ long ctuo_process(ctuo_t *c, const int16_t *pcm, long nsamples, float *rows, uns
         c->med_hidx = vs.hidx; /* VAD::clean() leaves both as they are */
         c->med_hsize = vs.hsize;
     }
-    if (is_trap && do_vad && !fail) { set_err(c, "oracle: trapdct together with VAD is not restated"); fail = 1; }
 
     free(x); free(fft_in); free(Xre); free(Xim); free(zr); free(zi); free(Xabs); free(Xph); free(Y); free(fvec);
     ctuo_cepdet_free(ss_det); free(ss_nr); free(ss_re); free(ss_im); free(ss_t); free(ss_w1); free(ss_w2);

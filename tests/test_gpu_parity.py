@@ -674,6 +674,29 @@ def test_apply_mode_silence(Engine):
         Engine("-fs 16000 -format_in raw -format_out raw -preset exten -vad_out_mode vad".split())
 
 
+@pytest.mark.parametrize("vadopts", ["-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode dyn",
+                                     "-vad burg -vad_out_mode vad -vad_cri_mode cepdist -vad_cepdist_mode lpc -vad_thr_mode adapt",
+                                     "-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode perc -vad_filter_order 5 -vad_apply_mode drop"])
+def test_vad_together_with_trapdct(Engine, vadopts):
+    """trapdctFEA::process_frame is false for the first half context and flush_frame delivers the last one (src/fea/fea_trap.cc:53-127), so
+    BATCH::save_frame - the detector, its majority filter and the writer (src/io/batch.cc:230-241) - runs half = (traplen - 1) / 2 frames
+    behind the input: call t reads the criterion of input frame min(t + half, T - 1).  Rows and every decision byte against the oracle."""
+    from ctucopy_amd import CtuError
+    cfg = C5 + vadopts.split()
+    utts = [sig("CS3"), synth_utt(71, 30000), synth_utt(72, 52 * 160 + 240)]   # the last one: 52 frames, one more than half a context
+    eng, orc = Engine(cfg), Oracle(cfg)
+    rows, vads = eng.extract(utts, want_vad=True)
+    ones = 0
+    for u, g, v in zip(utts, rows, vads):
+        ref, rv = orc.process(u, want_vad=True)
+        assert np.array_equal(v, rv)
+        assert g.shape == ref.shape and rel_err(g, ref) <= TOL
+        ones += int((rv == ord("1")).sum())
+    assert 0 < ones < sum(v.size for v in vads)   # both decisions occur
+    with pytest.raises(CtuError, match="TRAP vectors"):
+        Engine(C5 + "-vad_out_mode vad -vad_cri_mode cepdist -vad_cepdist_mode fea".split())
+
+
 def test_fuzz_found_configurations_at_the_noise_floor(Engine):
     """The two configurations of tools/probes/fuzz_configs.py (25 further seeds, profiles/r03_fuzz_configs.txt) that leave the 1e-4
     element-wise bound although they belong to the well-conditioned class, held to the bound they meet: 2e-4 element-wise and 1e-4 of

@@ -11,7 +11,11 @@ MEMORYLESS = "-vad_out_mode vad -vad_cri_mode energy -vad_thr_mode absolute -vad
 
 
 @pytest.mark.parametrize("chain,delay", [(["-fea_delta", "d"], 2), (["-fea_delta", "d_a"], 4), (["-fea_delta", "d_a_t"], 6),
-                                         (["-fea_delta", "d", "-d_win", "5"], 5), (["-fea_trap", "9"], 4)])
+                                         (["-fea_delta", "d", "-d_win", "5"], 5), (["-fea_trap", "9"], 4),
+                                         # trapdct: process_frame() is false for the first half context and flush_frame() delivers the last one
+                                         # (src/fea/fea_trap.cc:53-127): the same delayed writer, half = (traplen - 1) / 2 frames
+                                         (["-fb_definition", "23filters", "-fea_kind", "trapdct,101,16"], 50),
+                                         (["-fb_definition", "23filters", "-fea_kind", "trapdct,31,8"], 15)])
 def test_detector_behind_a_chain_sees_the_newest_input_frame(chain, delay):
     u = synth_utt(77, 30000)
     # pick a threshold that splits the frames: scan a few levels until both decisions occur in the plain run
