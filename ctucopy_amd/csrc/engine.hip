@@ -841,11 +841,23 @@ void build_tables(ctu_engine *e) {
         case ctu::FeaKind::None: e->feat = FEAT_BANDS; break;  // not reached: the signal path returns above
     }
     e->nz = e->mode ? (d.window + 15) / 16 : (d.window + 31) / 32;  // rows of samples per lane that can be non-zero
-    // The headline instantiation (frontend_kernel.h, DUAL) takes its window scaled by 1/2: the packed transform's untangle owes the
+    // The DUAL instantiations (frontend_kernel.h: the plain chain, with or without the intensity-loudness law) take their window scaled by 1/2: the packed transform's untangle owes the
     // power spectrum a factor 1/4, and a power of two on the window goes through every rounding of the chain unchanged - the rows are
     // bit for bit those of 0.25f * (re^2 + im^2), two multiplications per bin pair cheaper.  launch_vx checks that the instantiation
     // it launches is the one the table was scaled for.
-    e->half_window = CTU_DUAL && e->md && e->feat == FEAT_DCTC && !e->vf && !e->ss && !e->sy && e->mode == 0 && e->nz == 13 && d.o.nr_mode != "exten";
+    {   // the same decision tree as launch_vx, from the options
+        const ctu::Opts &o = d.o;
+        const bool vx = o.do_vad() && !e->vf && (o.vad_cri_mode == "energy" || (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "lpc"));
+        const bool base = !vx && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.nr_when_afterFB;
+        const bool exten = o.nr_mode == "exten", narrow = e->CW == 16;
+        bool dual = false;
+        if (e->md && e->feat == FEAT_LP) dual = true;
+        else if (e->md) dual = !exten;
+        else if (vx) dual = false;
+        else if (base && !o.fb_inld && !exten && e->feat != FEAT_LPD) dual = true;
+        else if (base && o.fb_inld && !exten && narrow && e->feat == FEAT_LP) dual = true;
+        e->half_window = CTU_DUAL && dual && !e->vf && !e->ss && !e->sy && !o.remove_dc1 && e->mode == 0 && e->nz == 13;
+    }
     if (e->half_window) {
         for (int l = 0; l < 16; l++)
             for (int j = 0; j < 32; j++) lc[(size_t)l * LANEC + LC_WIN + j] *= 0.5f;
@@ -898,7 +910,14 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     const bool narrow = kp.CW == 16;
     {   // the window table of this engine is scaled for exactly one instantiation (ctu_engine::half_window)
         constexpr bool dual_shape = CTU_DUAL && MODE == 0 && NZ < 16;
-        const bool dual = dual_shape && !(e->sy && kp.skip_phase2) && !kp.remove_dc1 && !e->ss && !e->vf && e->md && feat == FEAT_DCTC && !kp.nr_exten;
+        bool dual = false;  // does the tree below end on a DUAL instantiation (GEN_PLAIN or GEN_INLD without export / detector / synthesis)?
+        if (dual_shape && !(e->sy && kp.skip_phase2) && !kp.remove_dc1 && !e->ss && !e->vf) {
+            if (e->md && feat == FEAT_LP) dual = true;
+            else if (e->md) dual = !kp.nr_exten;
+            else if (vx) dual = false;
+            else if (base && !kp.fb_inld && !kp.nr_exten && feat != FEAT_LPD) dual = true;
+            else if (base && kp.fb_inld && !kp.nr_exten && narrow && feat == FEAT_LP) dual = true;
+        }
         if (dual != e->half_window) throw std::runtime_error("internal: window table scaled for another instantiation");
     }
     if (e->sy && kp.skip_phase2) {

@@ -195,8 +195,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
         // DUAL: the two passes of the 512-point mode run side by side (slots 0-3 and 4-7 of the step in lock step): each
         // table read serves both, and every stage offers the scheduler two independent instruction streams - the kernel
         // is bound by dependent latency (LDS round trips, transcendental-free but long FMA chains) at four waves per SIMD,
-        // not by issue.  The plain cepstral chain only (the headline instantiation).
-        constexpr bool DUAL = CTU_DUAL && MODE == 0 && GEN == GEN_PLAIN && MD && !VX && NZ < 16 && !VF && !SS && !SY;
+        // not by issue.  Every instantiation of the plain chain and of the plain chain + intensity-loudness law (round 4; rounds 2-3: the
+        // headline instantiation only): phase 1 does not depend on the feature tail.
+        constexpr bool DUAL = CTU_DUAL && MODE == 0 && (GEN == GEN_PLAIN || GEN == GEN_INLD) && !VX && NZ < 16 && !VF && !SS && !SY;
         if constexpr (DUAL && CTU_PK) {
             // The two passes as the two halves of packed registers: every add / multiply / FMA of phase 1 is a v_pk_*_f32 that
             // serves slots 0-3 and 4-7 together (kernel_common.h: cx2).  Same statements as the scalar DUAL block below.
