@@ -510,7 +510,19 @@ void build_phase2(const ctu::Design &d, Phase2Tables &t) {
         while (ft.size() & 3) ft.push_back(0.f);
     };
     t.ck_off = (int)ft.size();
-    push_ints(cell);
+    {   // the kernel's records: {first bin, band or -1, first chunk of the slot, chunks of the slot}; one more slot of idle cells, which
+        // the walk prefetches behind the last one
+        std::vector<int> rec4((size_t)(NS + 1) * 8 * 4, 0);
+        for (int sl = 0; sl <= NS; sl++)
+            for (int g = 0; g < 8; g++) {
+                int *r = &rec4[(size_t)(sl * 8 + g) * 4];
+                r[0] = sl < NS ? cell[(sl * 8 + g) * 2] : 0;
+                r[1] = sl < NS ? cell[(sl * 8 + g) * 2 + 1] : -1;
+                r[2] = slot_chunk[std::min(sl, NS)];
+                r[3] = sl < NS ? slot_chunk[sl + 1] - slot_chunk[sl] : 0;
+            }
+        push_ints(rec4);
+    }
     t.cf_off = (int)ft.size();
     if (!t.md) ft.insert(ft.end(), cf.begin(), cf.end());  // the MFMA tail reads the am table below instead
     while (ft.size() & 3) ft.push_back(0.f);

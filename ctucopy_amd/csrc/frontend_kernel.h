@@ -109,7 +109,6 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
     const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
     const int fg = lane >> 4;    // frame slot within the wave pass
     const int partner = ((lane & 48) | ((16 - l16) & 15)) << 2;  // byte address for ds_bpermute
-    ci32 *slot_chunk = as_const(p.itab);  // (row slots and the lifter, behind it in the tables, are lp_tail_kernel's)
     for (int i = tid; i < p.tab_floats; i += WG) ltab[i] = p.ftab[i];
     for (int i = tid; i < 16 * LANEC; i += WG) ltw[(i / LANEC) * LTW_STRIDE + (i % LANEC)] = p.lanec[i];
     // Phase 2 reads whole 4-bin chunks, so bins a frame never writes (row padding 257..259; everything above bin
@@ -1077,22 +1076,44 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     esum += ((k == 0 || k == p.K - 1) ? 0.5 : 1.0) * ((double)x * x);
                 }
             }
+            // A cell's record {first bin of its chunk run, band index or -1, first chunk of the slot, chunks of the slot} is the only
+            // per-lane indirection of a slot.  The next slot's record and this slot's DCT operands are fetched before the chunk walk
+            // starts, so no LDS round trip stands between two slots; the base addresses go through an empty asm, so the compiler
+            // addresses every chunk as base + immediate instead of re-deriving the table's address (a link-time LDS symbol plus an
+            // offset beyond the 16-bit field) with VALU adds per read.
+            typedef const __attribute__((address_space(3))) f32x4 lf4_t;
+            typedef const __attribute__((address_space(3))) int32x4 li4_t;
+            typedef const __attribute__((address_space(3))) float lf_t;
+            uint32_t cella = (uint32_t)(size_t)(lvoid_t *)(ltab + p.ck_off + g * 4);
+            uint32_t prowa = (uint32_t)(size_t)(lvoid_t *)prow2;
+            uint32_t wbasea = (uint32_t)(size_t)(lvoid_t *)(ltab + g * 4);
+            uint32_t ama = (uint32_t)(size_t)(lvoid_t *)(ltab + p.am_off + lane);
+            asm volatile("" : "+v"(cella), "+v"(prowa), "+v"(wbasea), "+v"(ama));
+            li4_t *cellp = (li4_t *)(size_t)cella;
+            lf_t *amp = (lf_t *)(size_t)ama;
+            int32x4 nxt = cellp[0];
             for (int sl = 0; sl < p.NS; sl++) {
-                const int cb = slot_chunk[sl], ce = slot_chunk[sl + 1];
-                // {first bin of the cell's chunk run, band index or -1}: the only per-lane indirection of the slot
-                const int kstart = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2]);
-                const int bidx = __float_as_int(ltab[p.ck_off + (sl * 8 + g) * 2 + 1]);
-                const float4 *pq = reinterpret_cast<const float4 *>(prow2 + kstart);  // kstart is a multiple of 4
-                const float4 *wq = reinterpret_cast<const float4 *>(ltab) + cb * 8 + g;
+                const int32x4 cur = nxt;
+                cellp += 8;
+                nxt = cellp[0];  // the table ends on a slot of idle cells
+                float a0 = 0.f, a1 = 0.f;
+                if constexpr (MD && !LPD) {
+                    a0 = amp[0];
+                    a1 = amp[64];
+                    amp += 128;
+                }
+                const int kstart = cur.x, bidx = cur.y;
+                const int nch = __builtin_amdgcn_readfirstlane(cur.w);
+                lf4_t *pq = (lf4_t *)(size_t)(prowa + 4u * (uint32_t)kstart);  // kstart is a multiple of 4
+                lf4_t *wq = (lf4_t *)(size_t)(wbasea + 128u * (uint32_t)cur.z);
                 float acc = 0.f, accb = 0.f;
-                const int nch = ce - cb;
                 int ch = 0;
                 for (; ch + 4 <= nch; ch += 4) {  // 4 chunks per group: 8 LDS reads in flight, then 16 FMAs
-                    float4 w4[4], p4[4];
+                    f32x4 w4[4], p4[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) w4[u] = wq[(ch + u) * 8];
+                    for (int u = 0; u < 4; u++) w4[u] = wq[u * 8];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) p4[u] = pq[ch + u];
+                    for (int u = 0; u < 4; u++) p4[u] = pq[u];
 #pragma unroll
                     for (int u = 0; u < 4; u += 2) {
                         acc += w4[u].x * p4[u].x;
@@ -1106,10 +1127,26 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // DS reads
                     __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU
+                    pq += 4;
+                    wq += 32;
                 }
-                for (; ch < nch; ch++) {
-                    const float4 w4 = wq[ch * 8];
-                    const float4 p4 = pq[ch];
+                if (nch & 2) {
+                    const f32x4 wa = wq[0], wb = wq[8];
+                    const f32x4 pa = pq[0], pb = pq[1];
+                    acc += wa.x * pa.x;
+                    accb += wa.y * pa.y;
+                    acc += wa.z * pa.z;
+                    accb += wa.w * pa.w;
+                    acc += wb.x * pb.x;
+                    accb += wb.y * pb.y;
+                    acc += wb.z * pb.z;
+                    accb += wb.w * pb.w;
+                    pq += 2;
+                    wq += 16;
+                }
+                if (nch & 1) {
+                    const f32x4 w4 = wq[0];
+                    const f32x4 p4 = pq[0];
                     acc += w4.x * p4.x;
                     accb += w4.y * p4.y;
                     acc += w4.z * p4.z;
@@ -1173,7 +1210,6 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     } else if constexpr (MD) {
                         // D[m][n] += sum_kk A[m][kk] B[kk][n]: B = this slot's band logarithms as they stand (n = lane & 15,
                         // kk = lane >> 4); A = DCT rows of the bands in groups kk (columns n < 8) or kk + 4 (columns n >= 8)
-                        const float a0 = ltab[p.am_off + (2 * sl) * 64 + lane], a1 = ltab[p.am_off + (2 * sl + 1) * 64 + lane];
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, y, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, y, acc1, 0, 0, 0);
                     } else {

@@ -58,7 +58,7 @@ struct KParams {
     const float *ftab;          // image of the LDS tables (tab_floats), then the lifter at lift_off
     const int *itab;            // slot_chunk[NS+1] | row_slot[nfea]
     // LDS tables (float index): chunk weights float4 [NC][8] at 0 | cell {first bin, band index or -1} (int2)
-    // [NS][8] at ck_off | per-cell coefficient rows [NS][8][CW] at cf_off
+    // [NS + 1][8] records of four ints at ck_off | per-cell coefficient rows [NS][8][CW] at cf_off
     int tab_floats, ck_off, cf_off, NS, CW;
     int cfd_off;                // FEAT_LPD: per-cell coefficient rows in double, [NS][8][CW] doubles (8-byte aligned)
     int ncoef_out;              // DCTC: coefficients written per row (table rows are in output order)
@@ -104,6 +104,7 @@ struct KParams {
 #define CTU_VF_A2C 1  // fused Burg-cepstral criterion: 1 = the front end stops at the lattice and vad_a2c_kernel finishes the cepstra (vad_fused.h); 0: the tail stays inside the front end (A/B)
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator
+typedef int int32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
