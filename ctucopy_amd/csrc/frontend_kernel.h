@@ -34,6 +34,9 @@ namespace {
 #ifndef CTU_ABL
 #define CTU_ABL 0       // diagnostic builds only (wrong results): bit 0 no lane-0 selects in the untangle, 1 no mean removal, 2 no imaginary
 #endif                  // transpose, 3 no mirror fetch, 4 no P stores of the mirror half, 5 no inter-stage twiddles, 6 no phase 2, 7 no second DFT: what a unit of VALU / LDS work costs
+#ifndef CTU_VF8
+#define CTU_VF8 1  // 0: the fused VAD criterion of the 256-point mode as two lattices of 16 lanes x 13 samples (A/B)
+#endif
 #ifndef CTU_BURG_UNROLL2
 #define CTU_BURG_UNROLL2 0  // 1: the two lattices of a 16-lane group unrolled into one block (the scheduler may interleave them)
 #endif
@@ -672,6 +675,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             // the VAD module's criterion (no Hann window, float): the lattice only - {alpha, k_m} go to the scratch rows and
             // vad_a2c_kernel finishes the cepstra one frame per lane; the *ss detector needs its cepstra here and now
             constexpr bool rc_only = CTU_VF_A2C && !decltype(HANN)::value && sizeof(real_t) == 4;
+            constexpr bool VF8 = CTU_VF8 && MODE == 1 && !decltype(HANN)::value && sizeof(real_t) == 4;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if constexpr (MODE == 1) {
@@ -690,6 +694,26 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (VF8) {
+                // the VAD module's criterion: the 200-sample window as 8 lanes x 25 samples, the step's eight frames in ONE lattice
+                // instead of two of four frames each (16 lanes x 13): the per-order sums, the division and the edge fix-ups are paid once
+                static_assert(VF_WINDOW == 8 * VF8_SPL, "");
+                const int f8v = lane >> 3, l8v = lane & 7;
+                const float *tx = Pw + f8v * VF_FSTRIDE + VF8_SPL * l8v;  // banks: 216 f + 25 l + j are distinct over a half wave
+                float x[VF8_SPL];
+                real_t cc[nco];
+#pragma unroll
+                for (int j = 0; j < VF8_SPL; j++) x[j] = tx[j];
+                vf_burg_cepstrum<nco, VF8_SPL - 1, real_t, VF8_SPL, rc_only, 8>(x, l8v, 7, VF8_SPL - 1, (real_t)p.inv_window_d, cc);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    real_t mine = cc[8 * h < nco ? 8 * h : 0];
+#pragma unroll
+                    for (int m = 1; m < 8; m++)
+                        if (8 * h + m < nco) mine = l8v == m ? cc[8 * h + m] : mine;
+                    out[h] = mine;  // lane 8 f + i: coefficients i and i + 8 of frame slot f
+                }
+            } else
 #if CTU_BURG_UNROLL2
 #pragma unroll
 #endif
@@ -1298,8 +1322,13 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 // 2 fg + x; 512-point mode: of frame slot 4 x + fg.
 #pragma unroll
                 for (int x = 0; x < 2; x++) {
-                    const int sl = MODE == 1 ? 2 * fg + x : 4 * x + fg;
-                    if (sl < nv && l16 < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + l16] = mine_ab[x];
+                    if constexpr (CTU_VF8 && MODE == 1) {  // lane 8 f + i: coefficients i and i + 8 of frame slot f
+                        const int sl = lane >> 3, ci = (lane & 7) + 8 * x;
+                        if (sl < nv && ci < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + ci] = mine_ab[x];
+                    } else {
+                        const int sl = MODE == 1 ? 2 * fg + x : 4 * x + fg;
+                        if (sl < nv && l16 < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + l16] = mine_ab[x];
+                    }
                 }
                 STAMP(13);  // VF: cepstra stored
             }

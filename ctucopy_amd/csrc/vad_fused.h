@@ -23,6 +23,7 @@ constexpr int SS_NC = 12;         // the *ss modes' detector uses -fea_ncepcoefs
 constexpr int VF_WINDOW = 200;    // the window the fused path is built for (8 kHz, 25 ms); other windows take the separate kernels
 constexpr int VF_SPL = 13;        // samples per lane of a frame: 16 lanes x 13 = 208 >= window
 constexpr int VF_LW = (VF_WINDOW - 1) / VF_SPL, VF_JW = (VF_WINDOW - 1) % VF_SPL;  // lane / register of the window's last sample
+constexpr int VF8_SPL = 25;       // the same window as 8 lanes x 25 samples (the VAD module's float lattice, frontend_kernel.h VF8)
 constexpr int VF_FSTRIDE = 216;   // floats per time-domain frame in the LDS staging area: 2 x 216 = 16 (mod 32), so the two
                                   // frame groups of a half wave read different banks; 8 x 216 <= the wave's 8 x 260
 // The 512-point mode (16 kHz, 25 ms): one frame per 16-lane group, four frames per half step
@@ -174,6 +175,9 @@ __device__ __forceinline__ void vf_inverse_fft(float2 (&vn)[16], const float4 *l
 // T = float (the VAD module's criterion: identical decisions to the double oracle on every test recording) or double
 // (the *ss modes' detector: it sees spectra raised to the power a, whose frames are nearly sinusoidal - reflection
 // coefficients within 1e-6 of +-1 - and a float lattice then loses the cepstra's digits that the threshold test needs).
+#ifndef CTU_BURG_RCP
+#define CTU_BURG_RCP 1  // 0: the reflection coefficient by the IEEE division sequence (A/B)
+#endif
 #ifndef CTU_BURG_DREC
 #define CTU_BURG_DREC 0  // 1: the denominator of order m+1 from that of order m, D' = (1 - k^2) D - f[m]^2 - b[N-1]^2, instead of the sum
 #endif
@@ -215,7 +219,9 @@ __device__ __forceinline__ void vf_lattice_to_cepstrum(T alpha, T (&a)[NC], T (&
 // RC_ONLY: stop at the lattice - cc[0] = the residual energy alpha, cc[m] = reflection coefficient of order m.  The coefficient
 // recursion (Burg.h:88-93) and a -> c (Burg.h:143-151) are one short sequential recursion per FRAME which all sixteen lanes of a
 // frame would repeat: vad_a2c_kernel (vad_kernels.h) finishes them one frame per lane, with these very expressions.
-template <int NC, int JW, class T, int SPL = VF_SPL, bool RC_ONLY = false>
+// LPF: lanes per frame.  16: a frame fills a DPP row; 8: two frames per row (the 200-sample window as 8 lanes x 25 samples, all eight
+// frames of a step in one call) - the sums then stay inside the half rows.
+template <int NC, int JW, class T, int SPL = VF_SPL, bool RC_ONLY = false, int LPF = 16>
 __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
     constexpr int VF_SPL = SPL;  // samples per lane (13: 256-point mode, 25: 512-point mode); shadows the global of the same name
     T ef[VF_SPL], eb[VF_SPL];
@@ -227,10 +233,16 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
         else part += ef[j] * ef[j];
     }
     auto row_sum = [](T v) {
-        v += dpp_mov<0x128>(v);  // row_ror:8
-        v += dpp_mov<0x124>(v);  // row_ror:4
-        v += dpp_mov<0x122>(v);  // row_ror:2
-        v += dpp_mov<0x121>(v);  // row_ror:1
+        if constexpr (LPF == 8) {
+            v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+            v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+            v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the half row
+        } else {
+            v += dpp_mov<0x128>(v);  // row_ror:8
+            v += dpp_mov<0x124>(v);  // row_ror:4
+            v += dpp_mov<0x122>(v);  // row_ror:2
+            v += dpp_mov<0x121>(v);  // row_ror:1
+        }
         return v;
     };
     T alpha = row_sum(part + part1) * inv_w;  // Energy.h:38-44 / Burg.h:62
@@ -253,8 +265,10 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
         {
             if (ik - 1 < VF_SPL) ef[ik - 1] = lane0 ? (T)0 : ef[ik - 1];
             if (ik >= 2 && ik - 2 < VF_SPL) eb[ik - 2] = lane0 ? (T)0 : eb[ik - 2];
-            const T eb_prev = dpp_mov<0x121>(eb[VF_SPL - 1]);  // row_ror:1
-            constexpr bool DREC = CTU_BURG_DREC && sizeof(T) == 4 && JW >= 0;
+            // row_ror:1: the lane before this one; a frame's first lane reads the last lane of a neighbour - the entry clear_last() keeps
+            // at zero (LPF = 8: SPL * LPF = window exactly) or a sample of the padding beyond the window (zero as well)
+            const T eb_prev = dpp_mov<0x121>(eb[VF_SPL - 1]);
+            constexpr bool DREC = CTU_BURG_DREC && sizeof(T) == 4 && JW >= 0 && LPF == 16;
             T n0 = 0, n1 = 0, d0 = 0, d1 = 0;
 #pragma unroll
             for (int j = 0; j < VF_SPL; j++) {
@@ -275,7 +289,16 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
             }
             const T num = row_sum(n0 + n1);
             const T den = (!DREC || ik == 1) ? row_sum(d0 + d1) : den_next;
-            const T rc = -((T)2 * num) / den;
+            T rc;
+            if constexpr (CTU_BURG_RCP && sizeof(T) == 4) {
+                // the float lattice's quotient by v_rcp_f32 and one correction of the quotient (the residual by FMA): as exact as the
+                // IEEE sequence for a denominator in the normal range (a sum of squares of samples), four instructions instead of ten
+                // on the chain every lane of the frame waits for
+                const float r = __builtin_amdgcn_rcpf(den), n2 = -2.f * num;
+                const float q = n2 * r;
+                rc = __builtin_fmaf(__builtin_fmaf(-den, q, n2), r, q);
+            } else
+                rc = -((T)2 * num) / den;
             alpha *= (T)1 - rc * rc;
             T carry = eb_prev;
 #pragma unroll
