@@ -676,6 +676,11 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             // vad_a2c_kernel finishes the cepstra one frame per lane; the *ss detector needs its cepstra here and now
             constexpr bool rc_only = CTU_VF_A2C && !decltype(HANN)::value && sizeof(real_t) == 4;
             constexpr bool VF8 = CTU_VF8 && MODE == 1 && !decltype(HANN)::value && sizeof(real_t) == 4;
+            // 1 / window: the float lattice's copy is wave-uniform and stays in an SGPR
+            auto inv_w_of = [&](auto z) {
+                if constexpr (sizeof(z) == 4) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)p.inv_window_d)));
+                else return p.inv_window_d;
+            };
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if constexpr (MODE == 1) {
@@ -704,15 +709,10 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 real_t cc[nco];
 #pragma unroll
                 for (int j = 0; j < VF8_SPL; j++) x[j] = tx[j];
-                vf_burg_cepstrum<nco, VF8_SPL - 1, real_t, VF8_SPL, rc_only, 8>(x, l8v, 7, VF8_SPL - 1, (real_t)p.inv_window_d, cc);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    real_t mine = cc[8 * h < nco ? 8 * h : 0];
-#pragma unroll
-                    for (int m = 1; m < 8; m++)
-                        if (8 * h + m < nco) mine = l8v == m ? cc[8 * h + m] : mine;
-                    out[h] = mine;  // lane 8 f + i: coefficients i and i + 8 of frame slot f
-                }
+                static_assert(rc_only && nco <= 16, "");
+                vf_burg_cepstrum<nco, VF8_SPL - 1, real_t, VF8_SPL, true, 8, true>(x, l8v, 7, VF8_SPL - 1, inv_w_of(real_t{}), cc);
+                out[0] = cc[0];  // lane 8 f + i: entries i and i + 8 of frame slot f
+                out[1] = cc[1];
             } else
 #if CTU_BURG_UNROLL2
 #pragma unroll
@@ -728,10 +728,12 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF_JW, real_t, VF_SPL, rc_only>(x, l16, VF_LW, VF_JW, (real_t)p.inv_window_d, cc);
+                vf_burg_cepstrum<nco, VF_JW, real_t, VF_SPL, rc_only, 16, rc_only>(x, l16, VF_LW, VF_JW, inv_w_of(real_t{}), cc);
                 real_t mine = cc[0];
+                if constexpr (!rc_only) {
 #pragma unroll
-                for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
+                    for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
+                }
                 out[xb] = mine;
             }
             } else {
@@ -765,10 +767,12 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF0_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL, rc_only>(x, l16, VF0_LW, VF0_JW, (real_t)p.inv_window_d, cc);
+                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL, rc_only, 16, rc_only>(x, l16, VF0_LW, VF0_JW, inv_w_of(real_t{}), cc);
                 real_t mine = cc[0];
+                if constexpr (!rc_only) {
 #pragma unroll
-                for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
+                    for (int m = 1; m < nco; m++) mine = l16 == m ? cc[m] : mine;
+                }
                 out[half] = mine;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();  // the staged frames are read before the next half overwrites them
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 if (FEAT == FEAT_BANDS) {
                     float *dst = p.band_to_scratch ? p.logmel : p.rows;
                     const int out_w = p.band_to_scratch ? p.B : p.D;
-                    if (bidx >= 0 && fvalid) dst[(rbase + fslot) * out_w + bidx] = y;
+                    if (bidx >= 0 && fvalid) uniform_ptr(dst + (rbase + slot0) * out_w)[(unsigned)(f8 * out_w + bidx)] = y;
                 } else {
                     if (FEAT == FEAT_LP && !o_fb_inld) y *= y;  // src/fea/fea_impl.cc:165-169
                     y = bidx >= 0 ? y : 0.f;  // idle cell: its log(0) must not meet the zero coefficients
@@ -1261,18 +1265,20 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     // rows of the table = lags of the cosine iDFT (src/fea/fea_impl.cc:181-198): lags 4j .. 4j+3 go to the frame's
                     // scratch row for lp_tail_kernel (Levinson-Durbin and a -> c, one frame per lane)
                     const int P_ = LPO ? LPO : p.lporder;
-                    float *rrow = reinterpret_cast<float *>(p.lp_r) + (rbase + fslot) * p.lp_stride + 4 * (lane >> 4);
+                    auto rrow = uniform_ptr(reinterpret_cast<float *>(p.lp_r) + (rbase + slot0) * p.lp_stride);
+                    const unsigned ro = (unsigned)(f8 * p.lp_stride + 4 * (lane >> 4));
                     if (fvalid && (lane & 8) == 0) {
 #pragma unroll
                         for (int r = 0; r < 4; r++)
-                            if (4 * (lane >> 4) + r <= P_) rrow[r] = o4[r];
+                            if (4 * (lane >> 4) + r <= P_) rrow[(size_t)ro + r] = o4[r];
                     }
                 } else {
-                    float *orow = p.rows + (rbase + fslot) * p.D + 4 * (lane >> 4);
+                    auto orow = uniform_ptr(p.rows + (rbase + slot0) * p.D);
+                    const unsigned ro = (unsigned)(f8 * p.D + 4 * (lane >> 4));
                     if (fvalid && (lane & 8) == 0) {
 #pragma unroll
                         for (int r = 0; r < 4; r++)
-                            if (4 * (lane >> 4) + r < p.ncoef_out) orow[r] = o4[r];
+                            if (4 * (lane >> 4) + r < p.ncoef_out) orow[(size_t)ro + r] = o4[r];
                     }
                 }
             } else if (FEAT == FEAT_DCTC || IS_LP) {
@@ -1323,11 +1329,13 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                 for (int x = 0; x < 2; x++) {
                     if constexpr (CTU_VF8 && MODE == 1) {  // lane 8 f + i: coefficients i and i + 8 of frame slot f
-                        const int sl = lane >> 3, ci = (lane & 7) + 8 * x;
-                        if (sl < nv && ci < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + ci] = mine_ab[x];
+                        int ln = lane;
+                        asm volatile("" : "+v"(ln));  // the lane's offset is two instructions: not worth a register across the whole step loop
+                        const int sl = ln >> 3, ci = (ln & 7) + 8 * x;
+                        if (sl < nv && ci < VF_NC) uniform_ptr(p.vad_cf + (rbase + slot0) * VFC_STRIDE)[(unsigned)(sl * VFC_STRIDE + ci)] = mine_ab[x];
                     } else {
                         const int sl = MODE == 1 ? 2 * fg + x : 4 * x + fg;
-                        if (sl < nv && l16 < VF_NC) p.vad_cf[(rbase + slot0 + sl) * VFC_STRIDE + l16] = mine_ab[x];
+                        if (sl < nv && l16 < VF_NC) uniform_ptr(p.vad_cf + (rbase + slot0) * VFC_STRIDE)[(unsigned)(sl * VFC_STRIDE + l16)] = mine_ab[x];
                     }
                 }
                 STAMP(13);  // VF: cepstra stored

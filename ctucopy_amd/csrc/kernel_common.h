@@ -107,6 +107,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // MFMA accumulator
 typedef int int32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
+// A pointer that is the same in every lane, pinned to SGPRs: stores through it take the scalar-base + 32-bit lane-offset form, so the
+// lane part is one VGPR of cheap arithmetic instead of a 64-bit product per lane (and nothing the register allocator has to spill).
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *uniform_ptr(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (__attribute__((address_space(1))) T *)(((unsigned long long)hi << 32) | lo);
+}
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

@@ -221,7 +221,9 @@ __device__ __forceinline__ void vf_lattice_to_cepstrum(T alpha, T (&a)[NC], T (&
 // frame would repeat: vad_a2c_kernel (vad_kernels.h) finishes them one frame per lane, with these very expressions.
 // LPF: lanes per frame.  16: a frame fills a DPP row; 8: two frames per row (the 200-sample window as 8 lanes x 25 samples, all eight
 // frames of a step in one call) - the sums then stay inside the half rows.
-template <int NC, int JW, class T, int SPL = VF_SPL, bool RC_ONLY = false, int LPF = 16>
+// RC_ONLY with FOLD: cc[h] of the frame's lane i ends up holding entry LPF h + i of {alpha, k_1 .. k_{NC-1}} - what that lane stores - and
+// every coefficient is dead as soon as its order is done (thirteen registers fewer across the lattice than keeping them for a final select).
+template <int NC, int JW, class T, int SPL = VF_SPL, bool RC_ONLY = false, int LPF = 16, bool FOLD = false>
 __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
     constexpr int VF_SPL = SPL;  // samples per lane (13: 256-point mode, 25: 512-point mode); shadows the global of the same name
     T ef[VF_SPL], eb[VF_SPL];
@@ -258,6 +260,10 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
     clear_last();
     T a[NC];
     T den_next = 0;
+    if constexpr (RC_ONLY && FOLD) {
+#pragma unroll
+        for (int h = 0; h < (NC + LPF - 1) / LPF; h++) cc[h] = 0;
+    }
 #pragma unroll
     for (int i = 0; i < NC; i++) a[i] = i == 0 ? (T)1 : (T)0;
 #pragma unroll
@@ -316,7 +322,8 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
                 den_next = ((T)1 - rc * rc) * den - row_sum(fe * fe + be * be);
             }
             clear_last();
-            if constexpr (RC_ONLY) cc[ik] = rc;
+            if constexpr (RC_ONLY && FOLD) cc[ik / LPF] = l16 == ik % LPF ? rc : cc[ik / LPF];
+            else if constexpr (RC_ONLY) cc[ik] = rc;
             else {
                 T an[NC];
 #pragma unroll
@@ -327,7 +334,8 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
             }
         }
     }
-    if constexpr (RC_ONLY) cc[0] = alpha;
+    if constexpr (RC_ONLY && FOLD) cc[0] = lane0 ? alpha : cc[0];
+    else if constexpr (RC_ONLY) cc[0] = alpha;
     else vf_lattice_to_cepstrum<NC, T, false>(alpha, a, cc);
 }
 
