@@ -234,7 +234,7 @@ std::string unsupported_reason(const ctu::Design &d) {
         // out by then and the next get_frame() rewrites the vector, so on every other chain the mode changes nothing - but these
         // modes seed the next file's noise estimate from that very vector (src/nr/nr.cc:212-221)
         if (o.vad_apply_mode == "silence") return "-vad_apply_mode silence together with hwss / fwss / 2fwss (it zeroes the vector the next file's noise estimate starts from)";
-        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., plain chain)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no VAD module beside it)";
     }
     if (o.nr_when_afterFB) {
         if (d.signal_out) return "-nr_when afterFB together with signal output";
@@ -365,11 +365,13 @@ bool ss_signal_eligible(const ctu::Design &d) {
 bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     if (d.signal_out) return ss_signal_eligible(d);
-    const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
+    // cepstra / LP coefficients in the sixteen-row accumulators, or band energies; everything behind the front end (the LP tail, delta /
+    // stacking, CMS, CMVN) runs on the rows of the last pass of the seed iteration
+    const bool lp = d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa;
+    const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || (lp && o.fea_lporder + 1 <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
     // -vad file=<f> (nr.cc:205-209, 297-302): the decisions come from a byte stream instead of the detector; same kernel, same frame shapes
     const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
-    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && !o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.fb_inld && !o.do_vad() && !d.signal_out &&
-           !o.rasta && d.post_order == 0 && !d.cms && !o.stat_cmvn && !o.apply_cmvn;
+    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && o.remove_dc && !o.remove_dc1 && !o.do_vad() && !d.signal_out && !o.rasta;
 }
 
 void build_phase2(const ctu::Design &d, Phase2Tables &t) {
@@ -948,7 +950,16 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     else if (e->ss) {
         if constexpr (MODE == 1 || NZ == 13) {
             if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
-            else if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
+            else if (feat == FEAT_BANDS && base && !kp.fb_inld) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
+            else if (!narrow) throw std::runtime_error("internal: SS engine without an SS instantiation");
+            // energy columns, -fb_inld, -fb_power off, the LP kinds: the flags at run time (the 25 ms frame shapes only: NZ = 13)
+            else if constexpr (NZ == 13) {
+                if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                else if (feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                else if (feat == FEAT_LP) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                else if (feat == FEAT_LPD) launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                else throw std::runtime_error("internal: SS engine without an SS instantiation");
+            }
             else throw std::runtime_error("internal: SS engine without an SS instantiation");
         }
         else throw std::runtime_error("internal: SS engine without an SS instantiation");

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
     constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
     static_assert(!MD || ((FEAT == FEAT_DCTC || FEAT == FEAT_LP) && NC == 16), "MD: DCT / cosine-iDFT tail with 16 coefficient rows");
     static_assert(!VF || !VX, "VF: no spectrum export");
-    static_assert(!SS || (!VX && !VF && (GEN == GEN_PLAIN || (SY && GEN == GEN_FULL))), "SS: plain chain, or signal output (magnitude spectra: run-time flags)");
+    static_assert(!SS || (!VX && !VF && (GEN == GEN_PLAIN || GEN == GEN_FULL)), "SS: the plain chain, or run-time flags (signal output, energy columns, -fb_inld, LP kinds, magnitude spectra)");
     static_assert(!((VF || SS) && MODE == 0) || NZ == 13, "VF / SS in the 512-point mode: 400-sample windows (16 lanes x 25 samples)");
     static_assert(!SY || (!VX && !VF && (GEN == GEN_FULL || GEN == GEN_DC1)), "SY: run-time flags, no export");
     const int o_e_mode = FULL ? p.e_mode : 0, o_dbg = FULL ? p.dbg : 0;
@@ -804,7 +804,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             if (nv > 0) {
                 // signal output: the NR works on magnitudes (-fb_power is forced off, src/io/opts.cc:285-288); all eight rows - a duplicate
                 // frame shares a complex transform with a real one and the synthesis reads both
+                // ... and so they do on the feature path under -fb_power off (src/io/in.cc:415-417 ahead of the NR, batch.cc:205-213)
                 if constexpr (SY) to_magnitude(0, (MODE == 1 || nv > 4) ? 8 : 4);
+                else to_magnitude(0, nv);
                 const bool two = p.ss_mode == 3;
                 const int utt = as_const(p.tile_utt)[tile];
                 if (rec.t0 == 0 && slot0 == 0) {  // new_file (nr.cc:212-221, 402-409): seed from the previous file's last vector
@@ -847,7 +849,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                 if (lane < nv) p.ss_vbits[rbase + slot0 + lane] = (unsigned char)((vbits >> lane) & 1u);
                 // (3) the spectra again, then the subtraction proper, frames in order, lane = bin
                 phase1(3);
+                // ... and so they do on the feature path under -fb_power off (src/io/in.cc:415-417 ahead of the NR, batch.cc:205-213)
                 if constexpr (SY) to_magnitude(0, (MODE == 1 || nv > 4) ? 8 : 4);
+                else to_magnitude(0, nv);
                 }
                 const float pp = p.nr_p, qq = 1.0f - p.nr_p;
                 for (int f = 0; f < nv; f++) {
