@@ -29,6 +29,11 @@ struct BigParams {
     int wfft, K, window, wshift, B, D, ncoef_out, feat, e_mode, e_slot;
     int remove_dc, fb_power, fb_inld, band_log, band_to_scratch, lp_is_lpa, lporder, ncep, lifter_on;
     float preem;
+    // wave1k_kernel with -nr_mode exten (src/nr/nr.cc:86-140): the recurrence runs along an utterance, so a wave walks a chain of whole
+    // utterances (the plan's per-wave chains: chain_first[n_chains], TileRec::next) instead of striding over the tile list
+    int nr_exten, n_chains;
+    const int *chain_first;
+    float nr_p, nr_a;
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red) {  // 256 threads; red: 4 doubles of LDS

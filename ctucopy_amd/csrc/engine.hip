@@ -284,7 +284,9 @@ std::string unsupported_reason(const ctu::Design &d) {
     }
     if (d.wfft >= 1024) {  // bigfft_kernel.h: the plain chain
         if (d.wfft > 4096) return "FFT size above 4096";
-        if (o.nr_mode != "none" || o.nr_when_afterFB) return "noise reduction with an FFT size above 512";
+        // exten on the spectrum at 1024 points: wave1k_kernel carries the recurrence along per-wave chains of utterances
+        const bool w1k_exten = d.wfft == 1024 && o.nr_mode == "exten" && !o.nr_when_afterFB && !d.signal_out && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
+        if ((o.nr_mode != "none" || o.nr_when_afterFB) && !w1k_exten) return "noise reduction with an FFT size above 512 (exten on 1024-point spectra excepted)";
         if (o.do_vad()) return "VAD with an FFT size above 512";
         if (o.remove_dc1) return "-remove_dc1 with an FFT size above 512";
         if (d.B > 64) return "more than 64 bands with an FFT size above 512";
@@ -1598,6 +1600,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             bp.lifter_on = kp.lifter_on; bp.preem = kp.preem;
             bp.fb_total = e->big_fb_total;
             bp.seg = e->big_seg.p;
+            bp.nr_exten = kp.nr_exten; bp.nr_p = kp.nr_p; bp.nr_a = kp.nr_a;
+            bp.chain_first = pl->wg_first.p; bp.n_chains = (int)pl->wg_first.n;
             const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8 + (size_t)d.wfft / 2 * 8 +
                                (size_t)((d.window + 3) & ~3) * 4 + (size_t)((e->big_fb_total + 3) & ~3) * 4 +
                                (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
@@ -1622,7 +1626,10 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                     e->attr_done.insert(wfn);
                 }
                 const int wper_cu = (int)std::max<size_t>(1, std::min<size_t>(CTU_W1K_LB * 4 / W1K_WAVES, (160 * 1024) / wshm));
-                const int wg = std::max(1, std::min((pl->n_tiles + W1K_WAVES - 1) / W1K_WAVES, e->n_cu * wper_cu));
+                if (bp.nr_exten && !e->per_wave) throw std::runtime_error("internal: exten without per-wave chains");
+                // exten: one wave per chain of utterances, every chain gets its wave whatever fits the chip at once
+                const int wg = bp.nr_exten ? std::max(1, (bp.n_chains + W1K_WAVES - 1) / W1K_WAVES)
+                                           : std::max(1, std::min((pl->n_tiles + W1K_WAVES - 1) / W1K_WAVES, e->n_cu * wper_cu));
                 hipLaunchKernelGGL(wave1k_kernel, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
             }
             else if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);

@@ -118,8 +118,17 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
     }
 
     const int gw = blockIdx.x * W1K_WAVES + wave, nw = gridDim.x * W1K_WAVES;
-    for (int tile = gw; tile < p.n_tiles; tile += nw) {
+    // exten state (src/nr/nr.cc:86-93): lane = bin (bins lane + 64 r, r < 8, and bin 512 with lane 0), carried along the wave's utterance
+    float navg[9], yavg[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        navg[r] = 0.95f;
+        yavg[r] = 0.05f;
+    }
+    int tile = p.nr_exten ? (gw < p.n_chains ? p.chain_first[gw] : -1) : (gw < p.n_tiles ? gw : -1);
+    while (tile >= 0) {
         const TileRec rec = load_rec(p.tiles, tile);
+        tile = p.nr_exten ? rec.next : (tile + nw < p.n_tiles ? tile + nw : -1);
         for (int f = 0; f < rec.nvalid; f++) {
             pcm4 q[8];  // samples x[i-2 .. i+1], i = 2 lane + 128 n2
             {
@@ -210,6 +219,44 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
             if (lane < 3) P[K + lane] = 0.f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (p.nr_exten) {
+                // extended spectral subtraction (src/nr/nr.cc:95-140), frontend_kernel's float recurrence: H = Navg / (Navg^a + Yavg^a)^(1/a),
+                // N = H X, Navg = p Navg + (1 - p) N, Yavg = |X - Navg|, X -= N written as X (1 - H) without the cancellation
+                if (rec.t0 + f == 0) {
+#pragma unroll
+                    for (int r = 0; r < 9; r++) {
+                        navg[r] = 0.95f;
+                        yavg[r] = 0.05f;
+                    }
+                }
+                const float pp = p.nr_p, qq = 1.0f - p.nr_p;
+#pragma unroll
+                for (int r = 0; r < 9; r++) {
+                    const int k = lane + 64 * r;
+                    const float X = k < K ? P[k] : 1.f;
+                    float H, omH;
+                    if (p.nr_a == 1.0f) {
+                        const float ir = __builtin_amdgcn_rcpf(navg[r] + yavg[r]);
+                        H = navg[r] * ir;
+                        omH = yavg[r] * ir;
+                    } else if (p.nr_a == 2.0f) {
+                        const float r2 = navg[r] * navg[r] + yavg[r] * yavg[r];
+                        const float ir = __builtin_amdgcn_rsqf(r2);
+                        const float rr = r2 * ir;
+                        H = navg[r] * ir;
+                        omH = (yavg[r] * yavg[r]) * __builtin_amdgcn_rcpf(rr * (rr + navg[r]));
+                    } else {
+                        H = navg[r] / powf(powf(navg[r], p.nr_a) + powf(yavg[r], p.nr_a), 1.0f / p.nr_a);
+                        omH = 1.0f - H;
+                    }
+                    const float N = H * X;
+                    navg[r] = pp * navg[r] + qq * N;
+                    yavg[r] = fabsf(X - navg[r]);
+                    if (k < K) P[k] = X * omH;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             double e_spec = 0.0;
             if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) (src/nr/nr.cc:36-45)
                 double s = 0.0;

@@ -261,6 +261,30 @@ def test_fft_sizes_above_512(Engine):
     _check(Engine, "-fs 48000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 64 -s 20".split(), u44)   # 3072 -> 4096
 
 
+@pytest.mark.parametrize("extra", [[], ["-fea_E", "on"], ["-nr_a", "2", "-nr_p", "0.9", "-fea_kind", "logspec"], ["-nr_a", "1.5", "-fea_delta", "d_a"]])
+def test_exten_at_1024_points(Engine, extra):
+    """-nr_mode exten on 40 ms frames at 16 kHz (640 samples -> 1024 points, src/io/opts.cc:277-280; VERDICT r03 missing #3 / next #6):
+    wave1k_kernel carries Navg / Yavg along per-wave chains of whole utterances.  Several utterances per chain and utterances longer
+    than a tile, so the reset at a file's first frame and the hand-over from tile to tile are both exercised."""
+    from ctucopy_amd import synth
+    cfg = C2 + ["-w", "40", "-s", "10", "-nr_mode", "exten"] + extra
+    utts = [sig("CS0")[:50000], synth_utt(61, 30000), sig("CS3")[:44000], synth_utt(62, 640), synth_utt(63, 9000)] + \
+           [synth.utterance_c(synth.SET_NOISY, i, True) for i in (3, 8)]
+    if "-fea_delta" in extra:
+        utts = [u for u in utts if u.size > 5000]  # the delta chain needs window + 2 frames (refused below that, as everywhere)
+    eng, orc = Engine(cfg), Oracle(cfg)
+    assert eng.kernel_name() == "wave1k_kernel"
+    got = eng.extract(utts)
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        _assert_rows(g, ref, cfg)
+    # order and batch do not matter: an utterance alone gives the same rows
+    alone = eng.extract([utts[2]])[0]
+    assert np.array_equal(alone, got[2])
+
+
+
 def test_vad_with_energy_column_cms_and_delta(Engine):
     # src/io/batch.cc:172-241: the detector is called when a vector reaches the writer - after CMS, and with a delta /
     # stacking chain on the criterion of the newest INPUT frame (delayed vectors, flushed frames); the writer reads the
