@@ -34,6 +34,9 @@ namespace {
 #ifndef CTU_ABL
 #define CTU_ABL 0       // diagnostic builds only (wrong results): bit 0 no lane-0 selects in the untangle, 1 no mean removal, 2 no imaginary
 #endif                  // transpose, 3 no mirror fetch, 4 no P stores of the mirror half, 5 no inter-stage twiddles, 6 no phase 2, 7 no second DFT: what a unit of VALU / LDS work costs
+#ifndef CTU_CAP_WAVES
+#define CTU_CAP_WAVES 1  // 0: the front end's instantiations may run more waves per SIMD than the launch is laid out for (A/B)
+#endif
 #ifndef CTU_VF8
 #define CTU_VF8 1  // 0: the fused VAD criterion of the 256-point mode as two lattices of 16 lanes x 13 samples (A/B)
 #endif
@@ -88,6 +91,13 @@ constexpr int fe_waves_per_simd(int mode, bool vf, bool ss, bool sy = false) {
 }
 
 template <int NZ, int FEAT, int MODE, bool VX, int NC, int GEN, int LPO = 0, bool MD = false, bool VF = false, bool SS = false, bool SY = false>
+#if CTU_CAP_WAVES
+// also the MOST waves per SIMD the register file is laid out for: a workgroup is eight waves and the grid is at most two workgroups per
+// CU (engine.hip: max_wg), i.e. four per SIMD when they are dealt evenly.  An instantiation that needs 96 registers or fewer would be
+// allowed five or six, and the dispatcher then fills SIMDs unevenly with the same sixteen waves (measured: the exten chains, which last
+// as long as their slowest wave, +22 .. +40 % when the kernel dropped from 97 to 96 registers)
+__attribute__((amdgpu_waves_per_eu(fe_waves_per_simd(MODE, VF, SS, SY), fe_waves_per_simd(MODE, VF, SS, SY))))
+#endif
 __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void frontend_kernel(const KParams p) {
     constexpr bool FULL = GEN == GEN_FULL || GEN == GEN_DC1;  // GEN_DC1 = GEN_FULL plus -remove_dc1 (its offsets cost registers the others need)
     static_assert(!MD || ((FEAT == FEAT_DCTC || FEAT == FEAT_LP) && NC == 16), "MD: DCT / cosine-iDFT tail with 16 coefficient rows");

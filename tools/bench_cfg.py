@@ -14,7 +14,8 @@ CFGS = {"C2": C2, "C3": C3, "C4": C4, "C4_novad": C4_NOVAD, "C5": C5, "C2_d_a": 
         "C2_vad16": C2 + "-vad burg -vad_out_mode vad -vad_cri_mode cepdist -vad_cepdist_mode lpc -vad_thr_mode adapt".split(),
         "C2_fwss16": C2 + "-vad burg -nr_mode fwss".split(),
         "C4_nc2": C4 + ["-vad_lpc_coefs", "2"], "C4_nc8": C4 + ["-vad_lpc_coefs", "8"],
-        "fft1024": C2 + ["-w", "40", "-s", "10"], "fft128": "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 16 -s 8".split(),
+        "fft1024": C2 + ["-w", "40", "-s", "10"], "fft1024_exten": C2 + ["-w", "40", "-s", "10", "-nr_mode", "exten"],
+        "C2_fwss16_E_d_a": C2 + "-vad burg -nr_mode fwss -fea_E on -fea_delta d_a".split(), "fft128": "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 16 -s 8".split(),
         "lp_noinld": C2 + "-fb_inld off -fea_kind lpc -fea_lporder 12 -fea_ncepcoefs 12".split(), "C2_dc1": C2 + ["-remove_dc1", "on"],
         "C2_d_a_cmvn": C2 + ["-fea_delta", "d_a", "-stat_cmvn", "x.stat", "-apply_cmvn", "x.stat"]}
 ap = argparse.ArgumentParser()

@@ -6,7 +6,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 : > $O/summary.csv
 echo '"config","kernel","calls","avg_ns","min_ns","max_ns"' >> $O/summary.csv
-for c in C2 C3 C4_novad C4 C4_10k C5 C2_vad16 C2_fwss16 C2_d_a C2_trap9 C2_cms_exp C2_cms_block exten_raw lp_noinld C2_dc1 fft128 fft1024; do
+for c in C2 C3 C4_novad C4 C4_10k C5 C2_vad16 C2_fwss16 C2_d_a C2_trap9 C2_cms_exp C2_cms_block exten_raw lp_noinld C2_dc1 fft128 fft1024 fft1024_exten C2_fwss16_E_d_a; do
   rm -rf $O/t_$c
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/t_$c -- python3 $R/tools/bench_cfg.py --cfg $c > $O/$c.log 2>&1 || { echo "failed $c"; exit 1; }
   f=$(find $O/t_$c -name "*kernel_stats.csv" | head -1)
