@@ -1620,7 +1620,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                                     (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
                                     (size_t)(((e->feat == FEAT_DCTC ? e->ncoef_out * d.B : 0) + 3) & ~3) * 4 + (size_t)((3 * d.B + 3) & ~3) * 4 + (size_t)(256 + 2 * d.B) * 4 + 64;
                 if (wshm > 160 * 1024) throw std::runtime_error("filter bank too wide for the LDS tables of the 1024-point kernel");
-                const void *wfn = (const void *)wave1k_kernel;
+                const void *wfn = bp.nr_exten ? (const void *)wave1k_kernel<true> : (const void *)wave1k_kernel<false>;
                 if (wshm > 64 * 1024 && !e->attr_done.count(wfn)) {
                     HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     e->attr_done.insert(wfn);
@@ -1630,7 +1630,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 // exten: one wave per chain of utterances, every chain gets its wave whatever fits the chip at once
                 const int wg = bp.nr_exten ? std::max(1, (bp.n_chains + W1K_WAVES - 1) / W1K_WAVES)
                                            : std::max(1, std::min((pl->n_tiles + W1K_WAVES - 1) / W1K_WAVES, e->n_cu * wper_cu));
-                hipLaunchKernelGGL(wave1k_kernel, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
+                if (bp.nr_exten) hipLaunchKernelGGL(wave1k_kernel<true>, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
+                else hipLaunchKernelGGL(wave1k_kernel<false>, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
             }
             else if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);
             else if (d.wfft == 2048) hipLaunchKernelGGL(bigfft_kernel<8>, dim3(g), dim3(256), shm, s, bp);

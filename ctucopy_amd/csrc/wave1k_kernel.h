@@ -50,7 +50,8 @@ __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     v[7] = make_float2(b[6].x - b[7].x, b[6].y - b[7].y);
 }
 
-constexpr int W1K_TS = 72;                       // dwords between the rows of the transpose plane
+constexpr int W1K_TS = 72;                       // dwords between the rows of the transpose plane (first transpose)
+constexpr int W1K_TS2 = 68;                      // ... of the second transpose
 constexpr int W1K_PLANE = 8 * W1K_TS;            // the plane: re and im of a transpose go through it one after the other; the power
                                                  // spectrum P[513 (+3)] takes its place once the transform is done
 constexpr int W1K_WAVE_FLOATS = W1K_PLANE + 64 + 64 + 64;  // plane / P | Y[64] | Ylog[64] | partial band sums [64]
@@ -63,7 +64,10 @@ constexpr int W1K_WAVES = CTU_W1K_WAVES;         // waves per workgroup
 
 // A frame is one wave's serial chain of ~40 LDS round trips: what hides them is other waves, so the kernel is built for five
 // per SIMD - twiddles come from one shared W1024 table instead of 48 registers per lane, samples are not fetched a frame ahead.
-__global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(const BigParams p, void *lp_r, int lp_stride) {
+// EXTEN: -nr_mode exten (the recurrence's eighteen state registers and the chain walk) as an instantiation of its own, one wave per SIMD
+// fewer: the plain kernel keeps its registers.
+template <bool EXTEN>
+__global__ __launch_bounds__(64 * W1K_WAVES, EXTEN ? CTU_W1K_LB - 1 : CTU_W1K_LB) void wave1k_kernel(const BigParams p, void *lp_r, int lp_stride) {
     extern __shared__ __align__(16) float smem[];
     constexpr int Nc = 512;
     const int K = p.K;  // 513
@@ -119,16 +123,16 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
 
     const int gw = blockIdx.x * W1K_WAVES + wave, nw = gridDim.x * W1K_WAVES;
     // exten state (src/nr/nr.cc:86-93): lane = bin (bins lane + 64 r, r < 8, and bin 512 with lane 0), carried along the wave's utterance
-    float navg[9], yavg[9];
+    float navg[EXTEN ? 9 : 1], yavg[EXTEN ? 9 : 1];
 #pragma unroll
-    for (int r = 0; r < 9; r++) {
+    for (int r = 0; r < (EXTEN ? 9 : 1); r++) {
         navg[r] = 0.95f;
         yavg[r] = 0.05f;
     }
-    int tile = p.nr_exten ? (gw < p.n_chains ? p.chain_first[gw] : -1) : (gw < p.n_tiles ? gw : -1);
+    int tile = EXTEN ? (gw < p.n_chains ? p.chain_first[gw] : -1) : (gw < p.n_tiles ? gw : -1);
     while (tile >= 0) {
         const TileRec rec = load_rec(p.tiles, tile);
-        tile = p.nr_exten ? rec.next : (tile + nw < p.n_tiles ? tile + nw : -1);
+        tile = EXTEN ? rec.next : (tile + nw < p.n_tiles ? tile + nw : -1);
         for (int f = 0; f < rec.nvalid; f++) {
             pcm4 q[8];  // samples x[i-2 .. i+1], i = 2 lane + 128 n2
             {
@@ -166,14 +170,14 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
                 }
             }
             // ---- 512-point complex FFT
-            auto exchange = [&](int wbase_, int wstep) {  // one transpose: every lane writes v[r] at wbase_ + wstep r and reads lane + 72 r
+            auto exchange = [&](int wbase_, int wstep, int rstride) {  // one transpose: every lane writes v[r] at wbase_ + wstep r and reads lane + rstride r
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < 8; r++) xpl[wbase_ + wstep * r] = v[r].x;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 8; r++) v[r].x = xpl[lane + W1K_TS * r];
+                for (int r = 0; r < 8; r++) v[r].x = xpl[lane + rstride * r];
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -181,18 +185,21 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 8; r++) v[r].y = xpl[lane + W1K_TS * r];
+                for (int r = 0; r < 8; r++) v[r].y = xpl[lane + rstride * r];
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             };
             dft8(v);
 #pragma unroll
             for (int r = 1; r < 8; r++) v[r] = cmul(v[r], lt1[8 * r + d1]);
-            exchange(d0 + W1K_TS * d1, 8);      // element (n0, n1, k2 = r) -> row n1, column n0 + 8 k2; then lane = n0 + 8 k2, register n1
+            exchange(d0 + W1K_TS * d1, 8, W1K_TS);      // element (n0, n1, k2 = r) -> row n1, column n0 + 8 k2; then lane = n0 + 8 k2, register n1
             dft8(v);
 #pragma unroll
             for (int r = 0; r < 8; r++) v[r] = cmul(v[r], lt2[64 * r + lane]);
-            exchange(d1 + W1K_TS * d0, 8);      // element (n0, k1 = r, k2) -> row n0, column k2 + 8 k1; then lane = k2 + 8 k1, register n0
+            // rows 68 dwords apart here: the row index is the lane's LOW digit, and 72 d0 = 8 d0 (mod 32) puts d0 and d0 + 4 of a half wave on
+            // one bank (a two-way conflict on all sixteen writes: 32 of the kernel's 162 conflict cycles per frame); 68 d0 = 4 d0 keeps the 32
+            // lanes of a half wave on 32 banks
+            exchange(d1 + W1K_TS2 * d0, 8, W1K_TS2);    // element (n0, k1 = r, k2) -> row n0, column k2 + 8 k1; then lane = k2 + 8 k1, register n0
             dft8(v);  // v[r] = Z[lane + 64 r]
             // ---- untangle the packed transform, |.|^2 (src/io/in.cc:388-394): bin k = lane + 64 r with Z[512 - k] from lane
             //      (64 - lane) % 64, register 7 - r (lane 0: register (8 - r) % 8, Z[512] = Z[0])
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(64 * W1K_WAVES, CTU_W1K_LB) void wave1k_kernel(cons
             if (lane < 3) P[K + lane] = 0.f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (p.nr_exten) {
+            if constexpr (EXTEN) {
                 // extended spectral subtraction (src/nr/nr.cc:95-140), frontend_kernel's float recurrence: H = Navg / (Navg^a + Yavg^a)^(1/a),
                 // N = H X, Navg = p Navg + (1 - p) N, Yavg = |X - Navg|, X -= N written as X (1 - H) without the cancellation
                 if (rec.t0 + f == 0) {
