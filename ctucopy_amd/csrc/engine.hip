@@ -234,7 +234,7 @@ std::string unsupported_reason(const ctu::Design &d) {
         // out by then and the next get_frame() rewrites the vector, so on every other chain the mode changes nothing - but these
         // modes seed the next file's noise estimate from that very vector (src/nr/nr.cc:212-221)
         if (o.vad_apply_mode == "silence") return "-vad_apply_mode silence together with hwss / fwss / 2fwss (it zeroes the vector the next file's noise estimate starts from)";
-        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no VAD module beside it)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no CMVN, no VAD module beside it)";
     }
     if (o.nr_when_afterFB) {
         if (d.signal_out) return "-nr_when afterFB together with signal output";
@@ -373,7 +373,10 @@ bool ss_eligible(const ctu::Design &d) {
     const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || (lp && o.fea_lporder + 1 <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
     // -vad file=<f> (nr.cc:205-209, 297-302): the decisions come from a byte stream instead of the detector; same kernel, same frame shapes
     const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
-    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && o.remove_dc && !o.remove_dc1 && !o.do_vad() && !d.signal_out && !o.rasta;
+    // CMVN is two passes over the list in the reference (statistics, then the rows): the second starts from the noise vector the first
+    // left behind, and no oracle restates that - refused rather than guessed
+    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && o.remove_dc && !o.remove_dc1 && !o.do_vad() && !d.signal_out && !o.rasta &&
+           !o.stat_cmvn && !o.apply_cmvn;
 }
 
 void build_phase2(const ctu::Design &d, Phase2Tables &t) {
