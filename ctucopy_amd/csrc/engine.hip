@@ -2314,7 +2314,8 @@ const char *ctu_engine_kernel_name(const ctu_engine *e) {
             const bool exten = o.nr_mode == "exten" && !o.nr_when_afterFB;
             const bool plain = plain_cepstral(d) || (!o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.nr_when_afterFB && !d.signal_out);
             n = "frontend_kernel<" + std::to_string(o.remove_dc1 ? 16 : e->nz) + ", " + feat + ", MODE " + std::to_string(e->mode) + ", " +
-                (e->sy ? "full" : !plain ? "full" : exten ? "exten" : o.fb_inld ? "inld" : "plain") + (e->md ? ", MD" : "") + (e->vf ? ", VF" : "") +
+                (e->sy ? "full" : !plain ? "full" : (e->ss && !(e->md && e->feat == FEAT_DCTC) && !(e->feat == FEAT_BANDS && !o.fb_inld)) ? "full" :  // launch_vx's *ss branch
+                 exten ? "exten" : o.fb_inld ? "inld" : "plain") + (e->md ? ", MD" : "") + (e->vf ? ", VF" : "") +
                 (e->ss ? ", SS" : "") + (e->sy ? ", SY" : "") + ">";
         }
         const_cast<ctu_engine *>(e)->kname = n;
