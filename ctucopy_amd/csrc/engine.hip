@@ -211,7 +211,7 @@ std::string unsupported_reason(const ctu::Design &d) {
             if (o.fea_E && o.fea_rawenergy) return "-remove_dc1 together with -fea_rawenergy";
         }
         if (o.nr_mode != "none" && o.nr_mode != "exten" && !ss_eligible(d))
-            return "hwss / fwss / 2fwss with signal output outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., DC removal on)";
+            return "hwss / fwss / 2fwss with signal output outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 2 to 16 cepstral coefficients or -vad file=..., DC removal on)";
         if (o.rasta) return "-nr_rasta";
         // BATCH only constructs its VAD on the feature paths (init_out, src/io/batch.cc:70-76); with signal output save_frame() calls
         // through the never-assigned pointer (batch.cc:230-241): the reference crashes, there is nothing to reproduce
@@ -234,7 +234,7 @@ std::string unsupported_reason(const ctu::Design &d) {
         // out by then and the next get_frame() rewrites the vector, so on every other chain the mode changes nothing - but these
         // modes seed the next file's noise estimate from that very vector (src/nr/nr.cc:212-221)
         if (o.vad_apply_mode == "silence") return "-vad_apply_mode silence together with hwss / fwss / 2fwss (it zeroes the vector the next file's noise estimate starts from)";
-        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 12 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no CMVN, no VAD module beside it)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 2 to 16 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no CMVN, no VAD module beside it)";
     }
     if (o.nr_when_afterFB) {
         if (d.signal_out) return "-nr_when afterFB together with signal output";
@@ -361,7 +361,7 @@ int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode 
 // and the enhanced frames go back to the time domain inside the front end (frontend_kernel<..., SS, SY>)
 bool ss_signal_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
-    const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
+    const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs >= 2 && o.fea_ncepcoefs <= SS_NC) || o.vadmode == "file";
     return CTU_SY && d.signal_out && ss_mode_of(o) && det_ok && fused_frame_shape(d) && o.remove_dc && !o.remove_dc1 && !o.rasta && !o.do_vad();
 }
 bool ss_eligible(const ctu::Design &d) {
@@ -372,7 +372,7 @@ bool ss_eligible(const ctu::Design &d) {
     const bool lp = d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa;
     const bool kind_ok = (d.kind == ctu::FeaKind::Dctc && d.nfea <= 16) || (lp && o.fea_lporder + 1 <= 16) || d.kind == ctu::FeaKind::Spec || d.kind == ctu::FeaKind::LogSpec;
     // -vad file=<f> (nr.cc:205-209, 297-302): the decisions come from a byte stream instead of the detector; same kernel, same frame shapes
-    const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs == SS_NC) || o.vadmode == "file";
+    const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs >= 2 && o.fea_ncepcoefs <= SS_NC) || o.vadmode == "file";
     // CMVN is two passes over the list in the reference (statistics, then the rows): the second starts from the noise vector the first
     // left behind, and no oracle restates that - refused rather than guessed
     return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && o.remove_dc && !o.remove_dc1 && !o.do_vad() && !d.signal_out && !o.rasta &&
@@ -954,7 +954,10 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     }
     else if (e->ss) {
         if constexpr (MODE == 1 || NZ == 13) {
-            if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
+            // the plain chain: the detector's lattice unrolled for the presets' 12 coefficients (LPO = 12) or for up to 16
+            if (e->md && feat == FEAT_DCTC && kp.ss_nc == 12) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 12, true, false, true>, grid, s, kp);
+            else if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
+            else if (feat == FEAT_BANDS && base && !kp.fb_inld && kp.ss_nc == 12) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 12, false, false, true>, grid, s, kp);
             else if (feat == FEAT_BANDS && base && !kp.fb_inld) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
             else if (!narrow) throw std::runtime_error("internal: SS engine without an SS instantiation");
             // energy columns, -fb_inld, -fb_power off, the LP kinds: the flags at run time (the 25 ms frame shapes only: NZ = 13)
@@ -1511,6 +1514,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         kp.vad_nc = e->vp.ncoef;
         kp.ss_mode = e->ss;
         kp.ss_init = d.o.nr_initsegs;
+        kp.ss_nc = d.o.fea_ncepcoefs;
         kp.han_off = e->han_off;
         kp.nr_b = (float)d.o.nr_b;
         kp.ss_q = d.o.nr_q;

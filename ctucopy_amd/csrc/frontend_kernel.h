@@ -738,7 +738,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF_JW, real_t, VF_SPL, rc_only, 16, rc_only>(x, l16, VF_LW, VF_JW, inv_w_of(real_t{}), cc);
+                vf_burg_cepstrum<nco, VF_JW, real_t, VF_SPL, rc_only, 16, rc_only>(x, l16, VF_LW, VF_JW, inv_w_of(real_t{}), cc, (decltype(HANN)::value && nco != 12) ? p.ss_nc : nco);  // the 12-coefficient instantiations: straight-line code, no order is skipped
                 real_t mine = cc[0];
                 if constexpr (!rc_only) {
 #pragma unroll
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF0_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL, rc_only, 16, rc_only>(x, l16, VF0_LW, VF0_JW, inv_w_of(real_t{}), cc);
+                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL, rc_only, 16, rc_only>(x, l16, VF0_LW, VF0_JW, inv_w_of(real_t{}), cc, (decltype(HANN)::value && nco != 12) ? p.ss_nc : nco);  // the 12-coefficient instantiations: straight-line code, no order is skipped
                 real_t mine = cc[0];
                 if constexpr (!rc_only) {
 #pragma unroll
@@ -845,7 +845,11 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     }
                 }
                 double mine_ab[2];
-                rebuild_cepstra(std::integral_constant<int, SS_NC>{}, std::true_type{}, mine_ab);
+                // the lattice is unrolled for SS_NC = 16 coefficients; the plain-chain instantiations also exist unrolled for the presets' 12
+                // (LPO = 12 marks them: the LP order it otherwise carries has no meaning for cepstra / band outputs) - fewer registers,
+                // and orders that follow each other without a branch in between
+                constexpr int SSN = (LPO == 12 && FEAT != FEAT_LP && FEAT != FEAT_LPD) ? 12 : SS_NC;
+                rebuild_cepstra(std::integral_constant<int, SSN>{}, std::true_type{}, mine_ab);
                 // (2) the detector's recurrences over the step's frames, in order (src/vdet/CepstralDet.h:140-194)
                 for (int s_ = 0; s_ < nv; s_++) {
                     // frame slot s_: group s_ / 2, frame s_ % 2 of it (256-point mode); group s_ % 4 of half s_ / 4 (512-point mode)
@@ -853,8 +857,8 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     const double sel = (MODE == 1 ? (s_ & 1) : (s_ >> 2)) ? mine_ab[1] : mine_ab[0];
                     const double got = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(sel)),
                                                         __builtin_amdgcn_ds_bpermute(src, __double2loint(sel)));
-                    const double cil = lane < SS_NC ? got : 0.0;
-                    vbits |= (unsigned)cepdet_frame(sdet, cil, lane, SS_NC, p.ss_init, p.nr_p_d, p.ss_q) << s_;
+                    const double cil = lane < p.ss_nc ? got : 0.0;
+                    vbits |= (unsigned)cepdet_frame(sdet, cil, lane, p.ss_nc, p.ss_init, p.nr_p_d, p.ss_q) << s_;
                 }
                 if (lane < nv) p.ss_vbits[rbase + slot0 + lane] = (unsigned char)((vbits >> lane) & 1u);
                 // (3) the spectra again, then the subtraction proper, frames in order, lane = bin

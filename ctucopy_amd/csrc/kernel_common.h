@@ -84,6 +84,7 @@ struct KParams {
     // the noise seeds of the utterances (the previous file's last vector) and where each utterance leaves its own,
     // the utterance of every tile, and the detector's Hann window [208] in the LDS tables
     int ss_mode, ss_init, han_off;
+    int ss_nc;                  // cepstral coefficients of the *ss modes' detector (-fea_ncepcoefs, src/nr/nr.cc:263-276): 2 .. SS_NC
     float nr_b;
     double ss_q;
     const float *ss_seed;

@@ -19,7 +19,8 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 }
 
 constexpr int VF_NC = 14;         // cepstral coefficients of the fused path (-vad_lpc_coefs default: Burg order 13)
-constexpr int SS_NC = 12;         // the *ss modes' detector uses -fea_ncepcoefs coefficients (src/nr/nr.cc:266-268): 12 in the presets
+constexpr int SS_NC = 16;         // the *ss modes' detector uses -fea_ncepcoefs coefficients (src/nr/nr.cc:266-268: 12 in the presets): the lattice is
+                                  // unrolled for up to 16 (one coefficient per lane of a frame's 16) and stops at the run-time count (KParams::ss_nc)
 constexpr int VF_WINDOW = 200;    // the window the fused path is built for (8 kHz, 25 ms); other windows take the separate kernels
 constexpr int VF_SPL = 13;        // samples per lane of a frame: 16 lanes x 13 = 208 >= window
 constexpr int VF_LW = (VF_WINDOW - 1) / VF_SPL, VF_JW = (VF_WINDOW - 1) % VF_SPL;  // lane / register of the window's last sample
@@ -223,8 +224,10 @@ __device__ __forceinline__ void vf_lattice_to_cepstrum(T alpha, T (&a)[NC], T (&
 // frames of a step in one call) - the sums then stay inside the half rows.
 // RC_ONLY with FOLD: cc[h] of the frame's lane i ends up holding entry LPF h + i of {alpha, k_1 .. k_{NC-1}} - what that lane stores - and
 // every coefficient is dead as soon as its order is done (thirteen registers fewer across the lattice than keeping them for a final select).
+// nc_rt: the number of coefficients wanted (<= NC, wave-uniform): orders nc_rt .. NC - 1 are skipped (their a[] stay zero and their
+// cepstra are not read).
 template <int NC, int JW, class T, int SPL = VF_SPL, bool RC_ONLY = false, int LPF = 16, bool FOLD = false>
-__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC]) {
+__device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16, int lw, int jw, T inv_w, T (&cc)[NC], int nc_rt = NC) {
     constexpr int VF_SPL = SPL;  // samples per lane (13: 256-point mode, 25: 512-point mode); shadows the global of the same name
     T ef[VF_SPL], eb[VF_SPL];
     T part = 0, part1 = 0;
@@ -268,7 +271,7 @@ __device__ __forceinline__ void vf_burg_cepstrum(const float (&x)[SPL], int l16,
     for (int i = 0; i < NC; i++) a[i] = i == 0 ? (T)1 : (T)0;
 #pragma unroll
     for (int ik = 1; ik < NC; ik++) {
-        {
+        if (ik < nc_rt) {
             if (ik - 1 < VF_SPL) ef[ik - 1] = lane0 ? (T)0 : ef[ik - 1];
             if (ik >= 2 && ik - 2 < VF_SPL) eb[ik - 2] = lane0 ? (T)0 : eb[ik - 2];
             // row_ror:1: the lane before this one; a frame's first lane reads the last lane of a neighbour - the entry clear_last() keeps

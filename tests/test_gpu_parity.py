@@ -921,6 +921,11 @@ def test_spectral_subtraction_at_16khz(Engine, extra):
     (8000, ["-nr_mode", "fwss", "-fb_eqld", "on", "-fb_inld", "on", "-fea_kind", "lpc", "-fea_lporder", "12"]),   # PLP behind the NR (LP tail kernel)
     (16000, ["-nr_mode", "fwss", "-fea_kind", "lpc", "-fea_lporder", "10", "-fea_E", "on"]),     # LP on uncompressed bands: the double tail
     (16000, ["-nr_mode", "fwss", "-fb_inld", "on", "-fea_trap", "5"]),                           # compressed bands into cepstra, stacked
+    (8000, ["-nr_mode", "fwss", "-fea_ncepcoefs", "10"]),                                        # the detector's order is -fea_ncepcoefs (nr.cc:263-276): 10,
+    (16000, ["-nr_mode", "fwss", "-fea_ncepcoefs", "15"]),                                       # 15 (the widest cepstral row of the 16-slot tail; plain chain),
+    (16000, ["-nr_mode", "fwss", "-fea_ncepcoefs", "14", "-fea_E", "on"]),                       # 14 with an energy column (run-time flags),
+    (16000, ["-nr_mode", "fwss", "-fea_kind", "logspec", "-fea_ncepcoefs", "16"]),               # 16 (band outputs: the count only steers the detector)
+    (8000, ["-nr_mode", "fwss", "-fea_kind", "spec", "-fea_ncepcoefs", "3"]),                    # and 3
 ])
 def test_spectral_subtraction_ahead_of_the_other_chains(Engine, fs, extra):
     """hwss / fwss / 2fwss in front of everything the plain chain can be followed by (VERDICT r03 missing #2): energy columns, -fb_inld,
@@ -993,7 +998,8 @@ def test_spectral_subtraction_more_utterances_than_chains(Engine):
 def test_spectral_subtraction_refusals(Engine):
     from ctucopy_amd import CtuError
     for cfg in (C2 + ["-nr_mode", "fwss", "-vad", "burg", "-w", "20"],        # a 320-sample window: not one of the fused frame shapes
-                SS8 + ["-nr_mode", "fwss", "-fea_ncepcoefs", "10"],          # detector order tied to -fea_ncepcoefs
+                SS8 + ["-nr_mode", "fwss", "-fea_kind", "spec", "-fea_ncepcoefs", "17"],   # detector order = -fea_ncepcoefs: up to 16 (round 4; 12 only before)
+                SS8 + ["-nr_mode", "fwss", "-stat_cmvn", "s.txt"],            # CMVN's two passes over the list
                 SS8 + ["-nr_mode", "hwss", "-nr_when", "afterFB"]):
         with pytest.raises(CtuError) as ei:
             Engine(cfg)
