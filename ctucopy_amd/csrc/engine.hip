@@ -211,7 +211,7 @@ std::string unsupported_reason(const ctu::Design &d) {
             if (o.fea_E && o.fea_rawenergy) return "-remove_dc1 together with -fea_rawenergy";
         }
         if (o.nr_mode != "none" && o.nr_mode != "exten" && !ss_eligible(d))
-            return "hwss / fwss / 2fwss with signal output outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 2 to 16 cepstral coefficients or -vad file=..., DC removal on)";
+            return "hwss / fwss / 2fwss with signal output outside the fused detector path (windows of 129 .. 208 samples on 256 points or 257 .. 400 on 512, -vad burg with 2 to 16 cepstral coefficients or -vad file=..., DC removal on)";
         if (o.rasta) return "-nr_rasta";
         // BATCH only constructs its VAD on the feature paths (init_out, src/io/batch.cc:70-76); with signal output save_frame() calls
         // through the never-assigned pointer (batch.cc:230-241): the reference crashes, there is nothing to reproduce
@@ -234,7 +234,7 @@ std::string unsupported_reason(const ctu::Design &d) {
         // out by then and the next get_frame() rewrites the vector, so on every other chain the mode changes nothing - but these
         // modes seed the next file's noise estimate from that very vector (src/nr/nr.cc:212-221)
         if (o.vad_apply_mode == "silence") return "-vad_apply_mode silence together with hwss / fwss / 2fwss (it zeroes the vector the next file's noise estimate starts from)";
-        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (25 ms frames at 8 or 16 kHz, -vad burg with 2 to 16 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no CMVN, no VAD module beside it)";
+        if (!ss_eligible(d)) return "hwss / fwss / 2fwss outside the fused detector path (windows of 129 .. 208 samples on 256 points or 257 .. 400 on 512, -vad burg with 2 to 16 cepstral coefficients or -vad file=..., DC removal on, at most 16 cepstral / LP coefficients, no trapdct, no -nr_when afterFB, no CMVN, no VAD module beside it)";
     }
     if (o.nr_when_afterFB) {
         if (d.signal_out) return "-nr_when afterFB together with signal output";
@@ -334,6 +334,11 @@ bool plain_cepstral(const ctu::Design &d) {
 bool fused_frame_shape(const ctu::Design &d) {
     return (d.wfft == 256 && d.window == VF_WINDOW) || (d.wfft == 512 && d.window == VF0_WINDOW);
 }
+// the *ss modes' detector: any window its lanes' 13 / 25 samples cover in the two transform sizes (the run-time-flag instantiations look
+// the window's end up at run time); the shapes above keep their straight-line instantiations on the plain chain
+bool ss_frame_shape(const ctu::Design &d) {
+    return (d.wfft == 256 && d.window > 128 && d.window <= 16 * VF_SPL) || (d.wfft == 512 && d.window > 256 && d.window <= 16 * VF0_SPL);
+}
 // Burg-cepstral VAD criterion fused into the front end (vad_fused.h): 14 coefficients (the preset's detector)
 bool vf_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
@@ -350,7 +355,10 @@ bool lp_md_eligible(const ctu::Design &d) {
     return CTU_MD && CTU_LP_MD && (d.kind == ctu::FeaKind::Lpc || d.kind == ctu::FeaKind::Lpa) && o.fb_inld && o.fea_lporder + 1 <= 16 && !o.nr_when_afterFB && !o.fea_E &&
            o.fb_power && o.remove_dc && !o.remove_dc1 && !d.signal_out && !o.do_vad() && o.nr_mode == "none";
 }
-bool md_eligible(const ctu::Design &d) { return (CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d))) || lp_md_eligible(d); }
+bool md_eligible(const ctu::Design &d) {
+    // (the *ss modes on another window than the presets' run the run-time-flag instantiation, which has no MFMA tail)
+    return (CTU_MD && plain_cepstral(d) && (!d.o.do_vad() || vf_eligible(d)) && !(ss_mode_of(d.o) && !fused_frame_shape(d))) || lp_md_eligible(d);
+}
 // hwss / fwss / 2fwss with the Burg cepstral detector (frontend_kernel<..., SS>): 25 ms frames at 8 or 16 kHz, the
 // presets' 12 cepstral coefficients for the detector, the plain chain into cepstra or band energies
 #ifndef CTU_SS_CACHE
@@ -362,7 +370,7 @@ int ss_mode_of(const ctu::Opts &o) { return o.nr_mode == "hwss" ? 1 : o.nr_mode 
 bool ss_signal_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
     const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs >= 2 && o.fea_ncepcoefs <= SS_NC) || o.vadmode == "file";
-    return CTU_SY && d.signal_out && ss_mode_of(o) && det_ok && fused_frame_shape(d) && o.remove_dc && !o.remove_dc1 && !o.rasta && !o.do_vad();
+    return CTU_SY && d.signal_out && ss_mode_of(o) && det_ok && ss_frame_shape(d) && o.remove_dc && !o.remove_dc1 && !o.rasta && !o.do_vad();
 }
 bool ss_eligible(const ctu::Design &d) {
     const ctu::Opts &o = d.o;
@@ -375,7 +383,7 @@ bool ss_eligible(const ctu::Design &d) {
     const bool det_ok = (o.vadmode == "burg" && o.fea_ncepcoefs >= 2 && o.fea_ncepcoefs <= SS_NC) || o.vadmode == "file";
     // CMVN is two passes over the list in the reference (statistics, then the rows): the second starts from the noise vector the first
     // left behind, and no oracle restates that - refused rather than guessed
-    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && fused_frame_shape(d) && kind_ok && o.remove_dc && !o.remove_dc1 && !o.do_vad() && !d.signal_out && !o.rasta &&
+    return CTU_MD && ss_mode_of(o) && det_ok && !o.nr_when_afterFB && ss_frame_shape(d) && kind_ok && o.remove_dc && !o.remove_dc1 && !o.do_vad() && !d.signal_out && !o.rasta &&
            !o.stat_cmvn && !o.apply_cmvn;
 }
 
@@ -955,7 +963,17 @@ void launch_vx(ctu_engine *e, dim3 grid, hipStream_t s, const KParams &kp) {
     else if (e->ss) {
         if constexpr (MODE == 1 || NZ == 13) {
             // the plain chain: the detector's lattice unrolled for the presets' 12 coefficients (LPO = 12) or for up to 16
-            if (e->md && feat == FEAT_DCTC && kp.ss_nc == 12) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 12, true, false, true>, grid, s, kp);
+            const bool preset_win = kp.window == (MODE == 1 ? VF_WINDOW : VF0_WINDOW);  // the straight-line lattices name the window's last sample
+            if (!preset_win) {
+                if constexpr (NZ == 13) {
+                    if (!narrow) throw std::runtime_error("internal: SS engine without an SS instantiation");
+                    if (feat == FEAT_BANDS) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                    else if (feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                    else if (feat == FEAT_LP) launch_fe(e, &frontend_kernel<NZ, FEAT_LP, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                    else launch_fe(e, &frontend_kernel<NZ, FEAT_LPD, MODE, false, 16, GEN_FULL, 0, false, false, true>, grid, s, kp);
+                } else throw std::runtime_error("internal: SS engine without an SS instantiation");
+            }
+            else if (e->md && feat == FEAT_DCTC && kp.ss_nc == 12) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 12, true, false, true>, grid, s, kp);
             else if (e->md && feat == FEAT_DCTC) launch_fe(e, &frontend_kernel<NZ, FEAT_DCTC, MODE, false, 16, GEN_PLAIN, 0, true, false, true>, grid, s, kp);
             else if (feat == FEAT_BANDS && base && !kp.fb_inld && kp.ss_nc == 12) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 12, false, false, true>, grid, s, kp);
             else if (feat == FEAT_BANDS && base && !kp.fb_inld) launch_fe(e, &frontend_kernel<NZ, FEAT_BANDS, MODE, false, 16, GEN_PLAIN, 0, false, false, true>, grid, s, kp);
@@ -1589,7 +1607,9 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
         }
         HIP_TRY(hipEventRecord(e->ev0, s));
         auto launch = [&] {
-            switch (kp.remove_dc1 ? 16 : e->nz) {
+            // (the 13-row instantiations serve every window of at most 13 rows - the window table is zero beyond the window - and the *ss
+            // modes are instantiated for 13 rows only)
+            switch (kp.remove_dc1 ? 16 : (e->ss && e->nz <= 13) ? 13 : e->nz) {
                 case 13: e->mode ? launch_vx<13, 1>(e, dim3(grid), s, kp) : launch_vx<13, 0>(e, dim3(grid), s, kp); break;
                 default: e->mode ? launch_vx<16, 1>(e, dim3(grid), s, kp) : launch_vx<16, 0>(e, dim3(grid), s, kp); break;
             }
@@ -2318,7 +2338,7 @@ const char *ctu_engine_kernel_name(const ctu_engine *e) {
             const bool exten = o.nr_mode == "exten" && !o.nr_when_afterFB;
             const bool plain = plain_cepstral(d) || (!o.fea_E && o.fb_power && o.remove_dc && !o.remove_dc1 && !o.nr_when_afterFB && !d.signal_out);
             n = "frontend_kernel<" + std::to_string(o.remove_dc1 ? 16 : e->nz) + ", " + feat + ", MODE " + std::to_string(e->mode) + ", " +
-                (e->sy ? "full" : !plain ? "full" : (e->ss && !(e->md && e->feat == FEAT_DCTC) && !(e->feat == FEAT_BANDS && !o.fb_inld)) ? "full" :  // launch_vx's *ss branch
+                (e->sy ? "full" : !plain ? "full" : (e->ss && (!fused_frame_shape(d) || (!(e->md && e->feat == FEAT_DCTC) && !(e->feat == FEAT_BANDS && !o.fb_inld)))) ? "full" :  // launch_vx's *ss branch
                  exten ? "exten" : o.fb_inld ? "inld" : "plain") + (e->md ? ", MD" : "") + (e->vf ? ", VF" : "") +
                 (e->ss ? ", SS" : "") + (e->sy ? ", SY" : "") + ">";
         }

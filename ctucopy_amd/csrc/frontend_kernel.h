@@ -541,9 +541,11 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
                     if (o_remove_dc) {
                         // mean of the windowed frame over `window` samples (src/io/in.cc:375-382)
                         const float m = row16_allreduce_add(dc) * p.inv_window;
-                        if (NZ == 16) {  // generic instantiation: any window <= 512, per-sample masks
+                        // generic instantiation: any window <= 512, per-sample masks.  The run-time-flag *ss instantiations exist for 13 rows
+                        // only and serve every window of at most 13 rows: masks as well (rows beyond the window would take the mean otherwise)
+                        if (NZ == 16 || (SS && FULL)) {
     #pragma unroll
-                            for (int j = 0; j < 16; j++) {
+                            for (int j = 0; j < NZ; j++) {
                                 const float4 mk = lc[(LC_MASK + 2 * j) >> 2];
                                 v[j].x -= m * ((j & 1) ? mk.z : mk.x);
                                 v[j].y -= m * ((j & 1) ? mk.w : mk.y);
@@ -686,6 +688,9 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
             // vad_a2c_kernel finishes the cepstra one frame per lane; the *ss detector needs its cepstra here and now
             constexpr bool rc_only = CTU_VF_A2C && !decltype(HANN)::value && sizeof(real_t) == 4;
             constexpr bool VF8 = CTU_VF8 && MODE == 1 && !decltype(HANN)::value && sizeof(real_t) == 4;
+            // the *ss detector of the run-time-flag instantiations takes the window at run time too (any window the lanes' 13 / 25 samples
+            // cover: up to 208 / 400): the lane and register of the window's last sample are looked up per order instead of being named
+            constexpr bool RTW = decltype(HANN)::value && GEN == GEN_FULL;
             // 1 / window: the float lattice's copy is wave-uniform and stays in an SGPR
             auto inv_w_of = [&](auto z) {
                 if constexpr (sizeof(z) == 4) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)p.inv_window_d)));
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF_JW, real_t, VF_SPL, rc_only, 16, rc_only>(x, l16, VF_LW, VF_JW, inv_w_of(real_t{}), cc, (decltype(HANN)::value && nco != 12) ? p.ss_nc : nco);  // the 12-coefficient instantiations: straight-line code, no order is skipped
+                vf_burg_cepstrum<nco, RTW ? -1 : VF_JW, real_t, VF_SPL, rc_only, 16, rc_only>(x, l16, RTW ? (p.window - 1) / VF_SPL : VF_LW, RTW ? (p.window - 1) % VF_SPL : VF_JW, inv_w_of(real_t{}), cc, (decltype(HANN)::value && nco != 12) ? p.ss_nc : nco);  // the 12-coefficient instantiations: straight-line code, no order is skipped
                 real_t mine = cc[0];
                 if constexpr (!rc_only) {
 #pragma unroll
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(WG, fe_waves_per_simd(MODE, VF, SS, SY)) void front
 #pragma unroll
                     for (int j = 0; j < VF0_SPL; j++) x[j] *= hw[j];
                 }
-                vf_burg_cepstrum<nco, VF0_JW, real_t, VF0_SPL, rc_only, 16, rc_only>(x, l16, VF0_LW, VF0_JW, inv_w_of(real_t{}), cc, (decltype(HANN)::value && nco != 12) ? p.ss_nc : nco);  // the 12-coefficient instantiations: straight-line code, no order is skipped
+                vf_burg_cepstrum<nco, RTW ? -1 : VF0_JW, real_t, VF0_SPL, rc_only, 16, rc_only>(x, l16, RTW ? (p.window - 1) / VF0_SPL : VF0_LW, RTW ? (p.window - 1) % VF0_SPL : VF0_JW, inv_w_of(real_t{}), cc, (decltype(HANN)::value && nco != 12) ? p.ss_nc : nco);  // the 12-coefficient instantiations: straight-line code, no order is skipped
                 real_t mine = cc[0];
                 if constexpr (!rc_only) {
 #pragma unroll

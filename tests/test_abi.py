@@ -78,7 +78,7 @@ def test_no_cpu_fallback():
 
 
 def test_unsupported_configurations_are_reported_not_approximated():
-    for cfg in (C2 + ["-dither", "1.0"], C2 + ["-nr_mode", "hwss", "-vad", "burg", "-w", "20"], C2 + ["-stat_cmvn", "stat.txt", "-fea_c0", "off"], C2 + ["-apply_cmvn", "s", "-fea_Z_exp", "500"],
+    for cfg in (C2 + ["-dither", "1.0"], C2 + ["-nr_mode", "hwss", "-vad", "burg", "-w", "30"], C2 + ["-stat_cmvn", "stat.txt", "-fea_c0", "off"], C2 + ["-apply_cmvn", "s", "-fea_Z_exp", "500"],
                 C2 + ["-fea_kind", "spec", "-fea_Z_exp", "500"],
                 C2 + ["-fea_delta", "d_a", "-fea_c0", "off"], C2 + ["-fea_kind", "logspec", "-fea_delta", "d"],
                 C2 + ["-fea_delta", "d", "-d_win", "17"],
