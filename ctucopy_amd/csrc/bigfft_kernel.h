@@ -34,6 +34,7 @@ struct BigParams {
     int nr_exten, n_chains;
     const int *chain_first;
     float nr_p, nr_a;
+    float *vad_en;           // wave1k_kernel: the VAD's energy criterion per frame (sum of squares of the vector the NR left, src/vad/vad.cc:96-107), or NULL
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red) {  // 256 threads; red: 4 doubles of LDS

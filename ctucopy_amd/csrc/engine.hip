@@ -287,7 +287,11 @@ std::string unsupported_reason(const ctu::Design &d) {
         // exten on the spectrum at 1024 points: wave1k_kernel carries the recurrence along per-wave chains of utterances
         const bool w1k_exten = d.wfft == 1024 && o.nr_mode == "exten" && !o.nr_when_afterFB && !d.signal_out && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
         if ((o.nr_mode != "none" || o.nr_when_afterFB) && !w1k_exten) return "noise reduction with an FFT size above 512 (exten on 1024-point spectra excepted)";
-        if (o.do_vad()) return "VAD with an FFT size above 512";
+        // the VAD on 1024-point frames: the criteria that need no spectrum behind the front end - the energy of the vector the NR left
+        // (wave1k_kernel stores it per frame) and the cepstral distance on the output vectors
+        const bool w1k_vad = d.wfft == 1024 && !d.signal_out && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0) &&
+                             (o.vad_cri_mode == "energy" || (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea"));
+        if (o.do_vad() && !w1k_vad) return "VAD with an FFT size above 512 (the energy criterion and -vad_cepdist_mode fea on 1024-point frames excepted)";
         if (o.remove_dc1) return "-remove_dc1 with an FFT size above 512";
         if (d.B > 64) return "more than 64 bands with an FFT size above 512";
     }
@@ -1628,6 +1632,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             bp.fb_total = e->big_fb_total;
             bp.seg = e->big_seg.p;
             bp.nr_exten = kp.nr_exten; bp.nr_p = kp.nr_p; bp.nr_a = kp.nr_a;
+            bp.vad_en = (e->do_vad && e->vp.cri == 0) ? pl->pnr.p : nullptr;
             bp.chain_first = pl->wg_first.p; bp.n_chains = (int)pl->wg_first.n;
             const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8 + (size_t)d.wfft / 2 * 8 +
                                (size_t)((d.window + 3) & ~3) * 4 + (size_t)((e->big_fb_total + 3) & ~3) * 4 +

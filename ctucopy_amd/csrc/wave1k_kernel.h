@@ -264,6 +264,17 @@ __global__ __launch_bounds__(64 * W1K_WAVES, EXTEN ? CTU_W1K_LB - 1 : CTU_W1K_LB
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            if (p.vad_en) {  // the VAD's energy criterion on the vector the NR left (frontend_kernel's vad_export == 2)
+                float es = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float x = P[lane + 64 * r];
+                    es += x * x;
+                }
+                if (lane == 0) es += P[Nc] * P[Nc];
+                const float tot = (float)wave_sum_fast((double)es);
+                if (lane == 0) p.vad_en[rec.rbase + f] = tot;
+            }
             double e_spec = 0.0;
             if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) (src/nr/nr.cc:36-45)
                 double s = 0.0;

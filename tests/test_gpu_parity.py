@@ -261,6 +261,18 @@ def test_fft_sizes_above_512(Engine):
     _check(Engine, "-fs 48000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 64 -s 20".split(), u44)   # 3072 -> 4096
 
 
+@pytest.mark.parametrize("extra", [["-vad_cri_mode", "energy", "-vad_thr_mode", "adapt"], ["-vad_cri_mode", "energy", "-vad_thr_mode", "dyn", "-nr_mode", "exten"],
+                                   ["-vad_cri_mode", "energy", "-vad_thr_mode", "perc", "-fea_delta", "d_a", "-vad_apply_mode", "drop"],
+                                   ["-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "adapt", "-vad_filter_order", "5"]])
+def test_vad_on_1024_point_frames(Engine, extra):
+    """The VAD module on 40 ms frames (VERDICT r03 missing #3): the criteria that need no spectrum behind the front end - the energy of
+    the vector the NR left (wave1k_kernel stores it per frame; with exten: after the subtraction, src/io/batch.cc:230-240) and the cepstral
+    distance on the output vectors; thresholds, majority filter, drop and the delayed detector behind a delta chain are the common path."""
+    cfg = C2 + ["-w", "40", "-s", "10", "-vad_out_mode", "vad"] + extra
+    utts = [sig("CS0")[:50000], synth_utt(71, 30000), sig("CS3")[:44000], synth_utt(73, 9000)]
+    _vad_agreement(Engine, cfg, utts, 1.0)
+
+
 @pytest.mark.parametrize("extra", [[], ["-fea_E", "on"], ["-nr_a", "2", "-nr_p", "0.9", "-fea_kind", "logspec"], ["-nr_a", "1.5", "-fea_delta", "d_a"]])
 def test_exten_at_1024_points(Engine, extra):
     """-nr_mode exten on 40 ms frames at 16 kHz (640 samples -> 1024 points, src/io/opts.cc:277-280; VERDICT r03 missing #3 / next #6):
