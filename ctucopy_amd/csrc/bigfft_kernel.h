@@ -45,7 +45,9 @@ __device__ __forceinline__ double block_sum(double v, double *red) {  // 256 thr
     return red[0] + red[1] + red[2] + red[3];
 }
 
-template <int NIT>  // wfft / 256: 4, 8 or 16 samples per lane
+// EXTEN: -nr_mode exten (src/nr/nr.cc:86-140) - the recurrence runs along an utterance, so a WORKGROUP walks one of the plan's chains of
+// whole utterances (chain_first / TileRec::next, as wave1k_kernel's waves do) with Navg / Yavg of its bins k = tid + 256 i in registers.
+template <int NIT, bool EXTEN = false>  // NIT = wfft / 256: 4, 8 or 16 samples per lane
 __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
     extern __shared__ __align__(16) float smem[];
     const int N = p.wfft, Nc = N >> 1, K = p.K;
@@ -73,8 +75,17 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
     for (int i = tid; i < ncf; i += 256) lcoef[i] = p.coef[i];
     for (int i = tid; i < 3 * p.B; i += 256) lrange[i] = p.fb_range[i];
     lds_barrier();
-    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    constexpr int NB = NIT / 2 + 1;  // bins per thread: K = 128 NIT + 1
+    float navg[EXTEN ? NB : 1], yavg[EXTEN ? NB : 1];
+#pragma unroll
+    for (int r = 0; r < (EXTEN ? NB : 1); r++) {
+        navg[r] = 0.95f;
+        yavg[r] = 0.05f;
+    }
+    int tile = EXTEN ? ((int)blockIdx.x < p.n_chains ? p.chain_first[blockIdx.x] : -1) : ((int)blockIdx.x < p.n_tiles ? (int)blockIdx.x : -1);
+    while (tile >= 0) {
         const TileRec rec = load_rec(p.tiles, tile);
+        tile = EXTEN ? rec.next : (tile + (int)gridDim.x < p.n_tiles ? tile + (int)gridDim.x : -1);
         // the samples of a frame are fetched one frame ahead (registers): the loads fly under the previous frame's passes
         int16_t cur[NIT], prv[NIT];
         auto fetch = [&](int f) {
@@ -152,6 +163,48 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                 P[k] = p.fb_power ? pw : sqrtf(pw);  // src/io/in.cc:415-417
             }
             lds_barrier();
+            if constexpr (EXTEN) {
+                // extended spectral subtraction, frontend_kernel's float recurrence (see wave1k_kernel.h): thread t owns bins t + 256 r
+                if (rec.t0 + f == 0) {
+#pragma unroll
+                    for (int r = 0; r < NB; r++) {
+                        navg[r] = 0.95f;
+                        yavg[r] = 0.05f;
+                    }
+                }
+                const float pp = p.nr_p, qq = 1.0f - p.nr_p;
+#pragma unroll
+                for (int r = 0; r < NB; r++) {
+                    const int k = tid + 256 * r;
+                    const float X = k < K ? P[k] : 1.f;
+                    float H, omH;
+                    if (p.nr_a == 1.0f) {
+                        const float ir = __builtin_amdgcn_rcpf(navg[r] + yavg[r]);
+                        H = navg[r] * ir;
+                        omH = yavg[r] * ir;
+                    } else if (p.nr_a == 2.0f) {
+                        const float r2 = navg[r] * navg[r] + yavg[r] * yavg[r];
+                        const float ir = __builtin_amdgcn_rsqf(r2);
+                        const float rr = r2 * ir;
+                        H = navg[r] * ir;
+                        omH = (yavg[r] * yavg[r]) * __builtin_amdgcn_rcpf(rr * (rr + navg[r]));
+                    } else {
+                        H = navg[r] / powf(powf(navg[r], p.nr_a) + powf(yavg[r], p.nr_a), 1.0f / p.nr_a);
+                        omH = 1.0f - H;
+                    }
+                    const float N = H * X;
+                    navg[r] = pp * navg[r] + qq * N;
+                    yavg[r] = fabsf(X - navg[r]);
+                    if (k < K) P[k] = X * omH;
+                }
+                lds_barrier();
+            }
+            if (p.vad_en) {  // the VAD's energy criterion on the vector the NR left (frontend_kernel's vad_export == 2)
+                double s = 0.0;
+                for (int k = tid; k < K; k += 256) s += (double)(P[k] * P[k]);
+                const double tot = block_sum(s, red);
+                if (tid == 0) p.vad_en[rec.rbase + f] = (float)tot;
+            }
             double e_spec = 0.0;
             if (p.e_mode == 1) {  // E = log(2 (X0^2/2 + sum X_i^2 + X_{K-1}^2/2)) (src/nr/nr.cc:36-45)
                 double s = 0.0;

@@ -285,13 +285,13 @@ std::string unsupported_reason(const ctu::Design &d) {
     if (d.wfft >= 1024) {  // bigfft_kernel.h: the plain chain
         if (d.wfft > 4096) return "FFT size above 4096";
         // exten on the spectrum at 1024 points: wave1k_kernel carries the recurrence along per-wave chains of utterances
-        const bool w1k_exten = d.wfft == 1024 && o.nr_mode == "exten" && !o.nr_when_afterFB && !d.signal_out && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
-        if ((o.nr_mode != "none" || o.nr_when_afterFB) && !w1k_exten) return "noise reduction with an FFT size above 512 (exten on 1024-point spectra excepted)";
+        // exten on the spectrum at 1024 .. 4096 points: wave1k_kernel / bigfft_kernel carry the recurrence along chains of whole utterances
+        const bool big_exten = o.nr_mode == "exten" && !o.nr_when_afterFB && !d.signal_out;
+        if ((o.nr_mode != "none" || o.nr_when_afterFB) && !big_exten) return "noise reduction with an FFT size above 512 (exten on the spectrum excepted)";
         // the VAD on 1024-point frames: the criteria that need no spectrum behind the front end - the energy of the vector the NR left
         // (wave1k_kernel stores it per frame) and the cepstral distance on the output vectors
-        const bool w1k_vad = d.wfft == 1024 && !d.signal_out && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0) &&
-                             (o.vad_cri_mode == "energy" || (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea"));
-        if (o.do_vad() && !w1k_vad) return "VAD with an FFT size above 512 (the energy criterion and -vad_cepdist_mode fea on 1024-point frames excepted)";
+        const bool big_vad = !d.signal_out && (o.vad_cri_mode == "energy" || (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea"));
+        if (o.do_vad() && !big_vad) return "VAD with an FFT size above 512 (the energy criterion and -vad_cepdist_mode fea excepted)";
         if (o.remove_dc1) return "-remove_dc1 with an FFT size above 512";
         if (d.B > 64) return "more than 64 bands with an FFT size above 512";
     }
@@ -1639,7 +1639,8 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                                (size_t)(e->feat == FEAT_LP ? (d.o.fea_lporder + 1) * d.B : 0) * 8 +
                                (size_t)(((e->feat == FEAT_DCTC ? e->ncoef_out * d.B : 0) + 3) & ~3) * 4 + (size_t)((3 * d.B + 3) & ~3) * 4 + 64 * 4;
             if (shm > 160 * 1024) throw std::runtime_error("filter bank too wide for the LDS tables of the large-FFT kernel");
-            const void *kfn = d.wfft == 1024 ? (const void *)bigfft_kernel<4> : d.wfft == 2048 ? (const void *)bigfft_kernel<8> : (const void *)bigfft_kernel<16>;
+            const void *kfn = kp.nr_exten ? (d.wfft == 1024 ? (const void *)bigfft_kernel<4, true> : d.wfft == 2048 ? (const void *)bigfft_kernel<8, true> : (const void *)bigfft_kernel<16, true>)
+                                          : (d.wfft == 1024 ? (const void *)bigfft_kernel<4> : d.wfft == 2048 ? (const void *)bigfft_kernel<8> : (const void *)bigfft_kernel<16>);
             if (shm > 64 * 1024 && !e->attr_done.count(kfn)) {
                 HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 e->attr_done.insert(kfn);
@@ -1665,9 +1666,16 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
                 if (bp.nr_exten) hipLaunchKernelGGL(wave1k_kernel<true>, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
                 else hipLaunchKernelGGL(wave1k_kernel<false>, dim3(wg), dim3(64 * W1K_WAVES), wshm, s, bp, (void *)pl->lp_r.p, d.o.fea_lporder + 1);
             }
-            else if (d.wfft == 1024) hipLaunchKernelGGL(bigfft_kernel<4>, dim3(g), dim3(256), shm, s, bp);
-            else if (d.wfft == 2048) hipLaunchKernelGGL(bigfft_kernel<8>, dim3(g), dim3(256), shm, s, bp);
-            else hipLaunchKernelGGL(bigfft_kernel<16>, dim3(g), dim3(256), shm, s, bp);
+            else if (bp.nr_exten) {  // one workgroup per chain of utterances
+                if (!e->per_wave) throw std::runtime_error("internal: exten without chains");
+                const dim3 gx((unsigned)std::max(1, bp.n_chains));
+                if (d.wfft == 1024) hipLaunchKernelGGL((bigfft_kernel<4, true>), gx, dim3(256), shm, s, bp);
+                else if (d.wfft == 2048) hipLaunchKernelGGL((bigfft_kernel<8, true>), gx, dim3(256), shm, s, bp);
+                else hipLaunchKernelGGL((bigfft_kernel<16, true>), gx, dim3(256), shm, s, bp);
+            }
+            else if (d.wfft == 1024) hipLaunchKernelGGL((bigfft_kernel<4>), dim3(g), dim3(256), shm, s, bp);
+            else if (d.wfft == 2048) hipLaunchKernelGGL((bigfft_kernel<8>), dim3(g), dim3(256), shm, s, bp);
+            else hipLaunchKernelGGL((bigfft_kernel<16>), dim3(g), dim3(256), shm, s, bp);
         }
         else if (!e->ss) launch();
         else {

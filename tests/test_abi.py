@@ -83,7 +83,7 @@ def test_unsupported_configurations_are_reported_not_approximated():
                 C2 + ["-fea_delta", "d_a", "-fea_c0", "off"], C2 + ["-fea_kind", "logspec", "-fea_delta", "d"],
                 C2 + ["-fea_delta", "d", "-d_win", "17"],
                 C2 + ["-w", "300"],                               # 4800 samples: an 8192-point FFT
-                C2 + ["-w", "100", "-nr_mode", "exten"],          # noise reduction with a 2048-point FFT (exten at 1024 points runs since round 4)
+                C2 + ["-w", "100", "-nr_mode", "exten", "-nr_when", "afterFB"],   # exten after the filter bank with a 2048-point FFT (on the spectrum it runs since round 4)
                 C2 + ["-w", "40", "-nr_mode", "fwss", "-vad", "burg"],   # the *ss modes with a 1024-point FFT
                 C2 + ["-nr_mode", "fwss", "-vad", "burg", "-stat_cmvn", "s.txt"],   # the *ss modes with CMVN's two passes over the list
                 C2 + ["-remove_dc1", "on", "-w", "25", "-s", "2"]):   # 12 frames over a sample

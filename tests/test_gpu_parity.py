@@ -261,6 +261,30 @@ def test_fft_sizes_above_512(Engine):
     _check(Engine, "-fs 48000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 64 -s 20".split(), u44)   # 3072 -> 4096
 
 
+@pytest.mark.parametrize("fs,extra", [(44100, ["-nr_mode", "exten"]), (44100, ["-nr_mode", "exten", "-nr_a", "2", "-fea_E", "on", "-fea_delta", "d"]),
+                                      (48000, ["-w", "64", "-s", "20", "-nr_mode", "exten", "-fea_kind", "logspec"]),
+                                      (44100, ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "adapt", "-nr_mode", "exten"]),
+                                      (48000, ["-w", "64", "-s", "20", "-vad_out_mode", "vad", "-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "dyn"])])
+def test_exten_and_vad_at_2048_and_4096_points(Engine, fs, extra):
+    """44.1 / 48 kHz audio: 25 ms are 1102 samples -> 2048 points, 64 ms at 48 kHz 3072 -> 4096 (src/io/opts.cc:277-280).  bigfft_kernel walks
+    the plan's chains of utterances with a workgroup each when exten is on, and stores the VAD's energy criterion per frame."""
+    cfg = f"-fs {fs} -format_in raw -format_out htk -preset mfcc -preem 0.97".split() + extra
+    utts = [synth_utt(130 + i, 40000 + 7111 * i) for i in range(3)] + [sig("CS0")[:50000], synth_utt(140, 1500 if fs == 44100 else 3200)]
+    if "-fea_delta" in extra:
+        utts = utts[:4]
+    if "-vad_out_mode" in extra:
+        _vad_agreement(Engine, cfg, utts, 1.0)
+        return
+    eng, orc = Engine(cfg), Oracle(cfg)
+    assert eng.kernel_name().startswith("bigfft_kernel")
+    got = eng.extract(utts)
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        _assert_rows(g, ref, cfg)
+    assert np.array_equal(eng.extract([utts[1]])[0], got[1])
+
+
 @pytest.mark.parametrize("extra", [["-vad_cri_mode", "energy", "-vad_thr_mode", "adapt"], ["-vad_cri_mode", "energy", "-vad_thr_mode", "dyn", "-nr_mode", "exten"],
                                    ["-vad_cri_mode", "energy", "-vad_thr_mode", "perc", "-fea_delta", "d_a", "-vad_apply_mode", "drop"],
                                    ["-vad_cri_mode", "cepdist", "-vad_cepdist_mode", "fea", "-vad_thr_mode", "adapt", "-vad_filter_order", "5"]])
