@@ -34,6 +34,8 @@ struct BigParams {
     int nr_exten, n_chains;
     const int *chain_first;
     float nr_p, nr_a;
+    const float *dc1;        // -remove_dc1 (bigfft_kernel): the frames' offsets (decode_kernels.h), or NULL; dc1_J = floor(window / wshift) <= 8
+    int dc1_J;
     float *vad_en;           // wave1k_kernel: the VAD's energy criterion per frame (sum of squares of the vector the NR left, src/vad/vad.cc:96-107), or NULL
 };
 
@@ -104,13 +106,29 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
             float *yb = reinterpret_cast<float *>(A);
             float partf = 0.f;  // a lane's 4..16 values in float (as the register kernels do), the block sum in double
             double raw = 0.0;
+            // -remove_dc1 (src/io/in.cc:343-350, decode_kernels.h): the sample at position i of frame t is read as
+            // x - o_t - sum_{j >= 1, i <= window-1-j*wshift} o_{t-j}; the sample ahead of the frame (position -1) without the o_t term
+            float ov[9];
+#pragma unroll
+            for (int j = 0; j <= 8; j++) ov[j] = (p.dc1 && j <= p.dc1_J && rec.t0 + f - j >= 0) ? p.dc1[rec.rbase + f - j] : 0.f;
+            auto dc1_cum = [&](int i, bool with_own) {
+                float c = with_own ? ov[0] : 0.f;
+#pragma unroll
+                for (int j = 1; j <= 8; j++) c += (j <= p.dc1_J && i <= p.window - 1 - j * p.wshift) ? ov[j] : 0.f;
+                return c;
+            };
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int i = tid + 256 * it;
                 float y = 0.f;
                 if (i < p.window) {
-                    const float xi = (float)cur[it];
-                    y = lwin[i] * (xi - p.preem * (float)prv[it]);
+                    float xi = (float)cur[it], xp = (float)prv[it];
+                    if (p.dc1) {
+                        xi -= dc1_cum(i, true);
+                        xp -= dc1_cum(i - 1, i >= 1);
+                        if (i == 0 && rec.t0 + f == 0) xp = 0.f;  // first sample of the file: history is 0
+                    }
+                    y = lwin[i] * (xi - p.preem * xp);
                     partf += y;
                     if (p.e_mode == 4 && i >= 1) raw += (double)xi * (double)xi;
                 }

@@ -292,7 +292,6 @@ std::string unsupported_reason(const ctu::Design &d) {
         // (wave1k_kernel stores it per frame) and the cepstral distance on the output vectors
         const bool big_vad = !d.signal_out && (o.vad_cri_mode == "energy" || (o.vad_cri_mode == "cepdist" && o.vad_cepdist_mode == "fea"));
         if (o.do_vad() && !big_vad) return "VAD with an FFT size above 512 (the energy criterion and -vad_cepdist_mode fea excepted)";
-        if (o.remove_dc1) return "-remove_dc1 with an FFT size above 512";
         if (d.B > 64) return "more than 64 bands with an FFT size above 512";
     }
     else if (d.wfft != 512 && d.wfft != 256) return "FFT size below 32";
@@ -783,7 +782,8 @@ void build_tables(ctu_engine *e) {
     const double pi = 3.14159265358979323846;
     e->big = d.wfft >= 1024;
     if (e->big) {
-        e->wave1k = d.wfft == 1024 && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
+        // (-remove_dc1 at 1024 points takes bigfft_kernel<4>, which reads the frames' offsets)
+        e->wave1k = d.wfft == 1024 && !d.o.remove_dc1 && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
         build_big_tables(e);
         return;
     }
@@ -1633,6 +1633,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             bp.seg = e->big_seg.p;
             bp.nr_exten = kp.nr_exten; bp.nr_p = kp.nr_p; bp.nr_a = kp.nr_a;
             bp.vad_en = (e->do_vad && e->vp.cri == 0) ? pl->pnr.p : nullptr;
+            bp.dc1 = kp.remove_dc1 ? pl->dc1.p : nullptr; bp.dc1_J = kp.dc1_J;
             bp.chain_first = pl->wg_first.p; bp.n_chains = (int)pl->wg_first.n;
             const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8 + (size_t)d.wfft / 2 * 8 +
                                (size_t)((d.window + 3) & ~3) * 4 + (size_t)((e->big_fb_total + 3) & ~3) * 4 +

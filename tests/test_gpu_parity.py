@@ -261,6 +261,27 @@ def test_fft_sizes_above_512(Engine):
     _check(Engine, "-fs 48000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -w 64 -s 20".split(), u44)   # 3072 -> 4096
 
 
+@pytest.mark.parametrize("fs,extra", [(16000, ["-w", "40", "-s", "10"]), (16000, ["-w", "40", "-s", "6", "-fea_E", "on", "-nr_mode", "exten"]),
+                                      (44100, ["-remove_dc", "off"]), (48000, ["-w", "64", "-s", "20", "-fea_kind", "logspec"])])
+def test_remove_dc1_above_512_points(Engine, fs, extra):
+    """-remove_dc1 (src/io/in.cc:343-350: the frame mean is subtracted from the sample buffer itself, so a sample carries the offsets of
+    every frame it has been part of) on 1024 .. 4096-point frames: bigfft_kernel reads the frames' offsets the two pre-pass kernels
+    leave, as the 512-point front end does.  A recording with a DC offset, so the option matters."""
+    cfg = f"-fs {fs} -format_in raw -format_out htk -preset mfcc -preem 0.97 -remove_dc1 on".split() + extra
+    dc = (sig("CS0")[:50000].astype(np.int32) + 700).clip(-32768, 32767).astype(np.int16)
+    utts = [synth_utt(150 + i, 40000 + 7111 * i) for i in range(2)] + [dc, synth_utt(153, 12000)]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    assert eng.kernel_name().startswith("bigfft_kernel")
+    got = eng.extract(utts)
+    for u, g in zip(utts, got):
+        ref = orc.process(u)
+        assert g.shape == ref.shape
+        _assert_rows(g, ref, cfg)
+    # the option does something on the offset recording: without it the rows differ
+    off = Engine([a if a != "on" or cfg[i - 1] != "-remove_dc1" else "off" for i, a in enumerate(cfg)]).extract([dc])[0]
+    assert not np.allclose(off, got[2], rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("fs,extra", [(44100, ["-nr_mode", "exten"]), (44100, ["-nr_mode", "exten", "-nr_a", "2", "-fea_E", "on", "-fea_delta", "d"]),
                                       (48000, ["-w", "64", "-s", "20", "-nr_mode", "exten", "-fea_kind", "logspec"]),
                                       (44100, ["-vad_out_mode", "vad", "-vad_cri_mode", "energy", "-vad_thr_mode", "adapt", "-nr_mode", "exten"]),
