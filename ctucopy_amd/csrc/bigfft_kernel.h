@@ -34,6 +34,8 @@ struct BigParams {
     int nr_exten, n_chains;
     const int *chain_first;
     float nr_p, nr_a;
+    float2 *xri;             // speech output (-format_out raw|wave): the frame's complex spectrum [K] and, in pnr, the magnitudes the NR left [K]
+    float *pnr;              // go to the plan's scratch for bigsynth_kernel; nothing is projected.  NULL on the feature path
     const float *dc1;        // -remove_dc1 (bigfft_kernel): the frames' offsets (decode_kernels.h), or NULL; dc1_J = floor(window / wshift) <= 8
     int dc1_J;
     float *vad_en;           // wave1k_kernel: the VAD's energy criterion per frame (sum of squares of the vector the NR left, src/vad/vad.cc:96-107), or NULL
@@ -164,12 +166,15 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
             // ---- untangle the packed transform, |.|^2 (src/io/in.cc:388-394), bins 0..Nc
             for (int k = tid; k <= Nc; k += 256) {
                 float pw;
+                float2 Xk;  // the bin itself (speech output keeps its direction)
                 if (k == 0) {
                     const float v = src[0].x + src[0].y;
                     pw = p.remove_dc ? 1e-10f : v * v;
+                    Xk = make_float2(v, 0.f);
                 } else if (k == Nc) {
                     const float v = src[0].x - src[0].y;
                     pw = v * v;
+                    Xk = make_float2(v, 0.f);
                 } else {
                     const float2 a = src[k], c = src[Nc - k], w = ltw[k];
                     const float sr = a.x + c.x, si = a.y - c.y, dr = a.x - c.x, di = a.y + c.y;
@@ -177,8 +182,10 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                     const float tr = w.x * di + w.y * dr, ti = w.y * di - w.x * dr;
                     const float ur = sr + tr, ui = si + ti;
                     pw = 0.25f * (ur * ur + ui * ui);
+                    Xk = make_float2(0.5f * ur, 0.5f * ui);
                 }
                 P[k] = p.fb_power ? pw : sqrtf(pw);  // src/io/in.cc:415-417
+                if (p.xri) p.xri[(rec.rbase + f) * K + k] = Xk;
             }
             lds_barrier();
             if constexpr (EXTEN) {
@@ -216,6 +223,11 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
                     if (k < K) P[k] = X * omH;
                 }
                 lds_barrier();
+            }
+            if (p.xri) {  // speech output: what the NR left of the magnitudes; the inverse transform is bigsynth_kernel's
+                for (int k = tid; k < K; k += 256) p.pnr[(rec.rbase + f) * K + k] = P[k];
+                lds_barrier();  // P and the FFT buffers are rewritten by the next frame
+                continue;
             }
             if (p.vad_en) {  // the VAD's energy criterion on the vector the NR left (frontend_kernel's vad_export == 2)
                 double s = 0.0;
@@ -335,6 +347,69 @@ __global__ __launch_bounds__(256) void bigfft_kernel(const BigParams p) {
             }
             lds_barrier();  // P, Y and the FFT buffers are rewritten by the next frame
         }
+    }
+}
+
+// Speech output on 1024 .. 4096-point frames (sigOUT, src/io/out.cc:405-434; signal_kernels.h has the 256 / 512-point form): a workgroup
+// per frame.  Every bin keeps its direction and takes the magnitude the NR left, times 1/N (DC and Nyquist as positive reals: the
+// reference stores them before its sign fix-up, out.cc:416-419); Hermitian -> real by the packed half-size inverse transform
+//   Z[k] = (X[k] + X*[M-k]) + i e^{+2 pi i k / N} (X[k] - X*[M-k]),  z = IDFT_M(Z),  y[2n] = Re z[n], y[2n+1] = Im z[n]
+// (bigfft_kernel's Stockham radix-2 passes with the conjugate twiddles); the first `window` samples go to the frame's scratch row,
+// which ola_kernel overlaps and adds.
+template <int NIT>
+__global__ __launch_bounds__(256) void bigsynth_kernel(const float2 *__restrict__ xri, const float *__restrict__ pnr, float *__restrict__ ybuf,
+                                                       long long total_frames, int wfft, int window, float inv_n, const float2 *__restrict__ tw) {
+    extern __shared__ __align__(16) float smem[];
+    const int Nc = wfft >> 1, K = Nc + 1, tid = threadIdx.x;
+    float2 *A = reinterpret_cast<float2 *>(smem);  // [Nc + 1]
+    float2 *Bf = A + Nc + 4;                       // [Nc]
+    float2 *ltw = Bf + Nc;                         // [Nc] (cos, -sin)(2 pi m / wfft)
+    for (int i = tid; i < Nc; i += 256) ltw[i] = tw[i];
+    lds_barrier();
+    for (long long f = blockIdx.x; f < total_frames; f += gridDim.x) {
+        const float2 *xr = xri + f * K;
+        const float *pn = pnr + f * K;
+        for (int k = tid; k <= Nc; k += 256) {
+            float2 v;
+            if (k == 0 || k == Nc) v = make_float2(pn[k] * inv_n, 0.f);
+            else {
+                const float2 x0 = xr[k];
+                const float mag2 = x0.x * x0.x + x0.y * x0.y;
+                const float sc = mag2 > 0.f ? pn[k] * inv_n * rsqrtf(mag2) : 0.f;
+                v = make_float2(x0.x * sc, x0.y * sc);
+            }
+            A[k] = v;
+        }
+        lds_barrier();
+        for (int k = tid; k < Nc; k += 256) {
+            const float2 a = A[k], b = A[Nc - k];
+            const float2 sm = make_float2(a.x + b.x, a.y - b.y);  // X[k] + conj(X[M-k])
+            const float2 df = make_float2(a.x - b.x, a.y + b.y);  // X[k] - conj(X[M-k])
+            const float2 w = make_float2(ltw[k].x, -ltw[k].y);    // e^{+2 pi i k / N}
+            const float2 t = make_float2(-(w.x * df.y + w.y * df.x), w.x * df.x - w.y * df.y);  // i w df
+            Bf[k] = make_float2(sm.x + t.x, sm.y + t.y);
+        }
+        lds_barrier();
+        float2 *src = Bf, *dst = A;
+        for (int Ns = 1; Ns < Nc; Ns <<= 1) {
+            const int tstep = Nc / Ns;  // conj of W_{2Ns}^k = W_wfft^(k * Nc / Ns)
+            for (int j = tid; j < (Nc >> 1); j += 256) {
+                const int k = j & (Ns - 1);
+                const float2 w = make_float2(ltw[k * tstep].x, -ltw[k * tstep].y);
+                const float2 a = src[j], b0 = src[j + (Nc >> 1)];
+                const float2 b = make_float2(b0.x * w.x - b0.y * w.y, b0.x * w.y + b0.y * w.x);
+                const int j0 = ((j - k) << 1) + k;
+                dst[j0] = make_float2(a.x + b.x, a.y + b.y);
+                dst[j0 + Ns] = make_float2(a.x - b.x, a.y - b.y);
+            }
+            lds_barrier();
+            float2 *t_ = src;
+            src = dst;
+            dst = t_;
+        }
+        float *yo = ybuf + f * window;  // any window: 25 ms at 44.1 kHz are 1103 samples, rows of odd length are not 8-byte aligned
+        for (int n = tid; n < window; n += 256) yo[n] = (n & 1) ? src[n >> 1].y : src[n >> 1].x;
+        lds_barrier();
     }
 }
 

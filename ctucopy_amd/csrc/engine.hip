@@ -216,8 +216,12 @@ std::string unsupported_reason(const ctu::Design &d) {
         // BATCH only constructs its VAD on the feature paths (init_out, src/io/batch.cc:70-76); with signal output save_frame() calls
         // through the never-assigned pointer (batch.cc:230-241): the reference crashes, there is nothing to reproduce
         if (o.do_vad()) return "VAD together with signal output (the reference dereferences a VAD it never constructs there, src/io/batch.cc:62-66,230-241)";
-        if (d.wfft != 512 && d.wfft != 256) return "FFT size other than 512 or 256";
-        if (d.window % 2) return "odd window length with signal output";
+        if (d.wfft > 4096) return "FFT size above 4096";
+        if (d.wfft >= 1024) {  // bigfft_kernel exports the spectra, bigsynth_kernel transforms back: the plain chain and exten
+            if (o.nr_mode != "none" && o.nr_mode != "exten") return "hwss / fwss / 2fwss with signal output at an FFT size above 512";
+        }
+        else if (d.wfft != 512 && d.wfft != 256) return "signal output at an FFT size below 256";
+        if (d.window % 2 && d.wfft < 1024) return "odd window length with signal output at an FFT size below 1024";
         if (d.window < 32) return "window shorter than 32 samples";
         return "";
     }
@@ -783,7 +787,7 @@ void build_tables(ctu_engine *e) {
     e->big = d.wfft >= 1024;
     if (e->big) {
         // (-remove_dc1 at 1024 points takes bigfft_kernel<4>, which reads the frames' offsets)
-        e->wave1k = d.wfft == 1024 && !d.o.remove_dc1 && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);
+        e->wave1k = d.wfft == 1024 && !d.o.remove_dc1 && !d.signal_out && !(getenv("CTU_WAVE1K") && atoi(getenv("CTU_WAVE1K")) == 0);  // (and speech output: the spectra's export is bigfft_kernel's)
         build_big_tables(e);
         return;
     }
@@ -1634,6 +1638,7 @@ int ctu_engine_run(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pcm, floa
             bp.nr_exten = kp.nr_exten; bp.nr_p = kp.nr_p; bp.nr_a = kp.nr_a;
             bp.vad_en = (e->do_vad && e->vp.cri == 0) ? pl->pnr.p : nullptr;
             bp.dc1 = kp.remove_dc1 ? pl->dc1.p : nullptr; bp.dc1_J = kp.dc1_J;
+            bp.xri = signal ? pl->xri.p : nullptr; bp.pnr = signal ? pl->pnr.p : nullptr;
             bp.chain_first = pl->wg_first.p; bp.n_chains = (int)pl->wg_first.n;
             const size_t shm = (size_t)d.wfft * 8 + (size_t)((d.K + 3) & ~3) * 4 + 64 * 4 + 4 * 8 + (size_t)d.wfft / 2 * 8 +
                                (size_t)((d.window + 3) & ~3) * 4 + (size_t)((e->big_fb_total + 3) & ~3) * 4 +
@@ -2232,7 +2237,23 @@ int ctu_engine_run_signal(ctu_engine *e, const ctu_plan *pl, const int16_t *d_pc
         sp.K = d.K; sp.wfft = d.wfft; sp.window = d.window; sp.wshift = d.wshift;
         sp.inv_n = 1.0f / (float)d.wfft;
         sp.corr = d.ola_corr;
-        if (pl->total_frames > 0 && !e->sy) {
+        if (pl->total_frames > 0 && e->big) {
+            // 1024 .. 4096 points: a workgroup per frame, LDS: two buffers of wfft / 2 (+ 4) complex values and the twiddles
+            const size_t shm = ((size_t)(d.wfft / 2) * 3 + 8) * sizeof(float2);
+            const int g = (int)std::min<int64_t>(pl->total_frames, (int64_t)e->n_cu * 8);
+#define BIGSYNTH(NIT_)                                                                                                              \
+    do {                                                                                                                            \
+        if (shm > 64 * 1024) allow_big_lds(e, &bigsynth_kernel<NIT_>);                                                              \
+        hipLaunchKernelGGL((bigsynth_kernel<NIT_>), dim3(g), dim3(256), shm, s, pl->xri.p, pl->pnr.p, pl->ybuf.p, (long long)pl->total_frames, \
+                           d.wfft, d.window, sp.inv_n, e->big_tw.p);                                                                \
+    } while (0)
+            if (d.wfft == 1024) BIGSYNTH(4);
+            else if (d.wfft == 2048) BIGSYNTH(8);
+            else BIGSYNTH(16);
+#undef BIGSYNTH
+            HIP_TRY(hipGetLastError());
+        }
+        else if (pl->total_frames > 0 && !e->sy) {
             const int g = (int)std::min<int64_t>((pl->total_frames + 7) / 8, (int64_t)e->n_cu * 8);
             hipLaunchKernelGGL(synth_kernel, dim3(g), dim3(256), 0, s, pl->xri.p, pl->pnr.p, pl->ybuf.p, (long long)pl->total_frames, sp);
             HIP_TRY(hipGetLastError());

@@ -689,6 +689,27 @@ def test_spectral_subtraction_with_signal_output_and_decisions_from_a_file(Engin
         assert g.shape == ref.shape and d.max() <= 2 and d.mean() <= 0.3
 
 
+@pytest.mark.parametrize("cfg", ["-fs 44100 -format_in raw -format_out raw -w 24 -s 12.5 -nr_mode exten",       # 1058 samples: 2048 points
+                                 "-fs 16000 -format_in raw -format_out raw -w 40 -s 20 -nr_mode exten -nr_a 2",  # 640 samples: 1024 points
+                                 "-fs 48000 -format_in raw -format_out raw -w 64 -s 16",                         # 3072 samples: 4096 points, no NR
+                                 "-fs 44100 -format_in raw -format_out raw -w 24 -s 12.5 -nr_mode exten -remove_dc1 on",
+                                 "-fs 44100 -format_in raw -format_out raw -w 25 -s 10 -nr_mode exten"])                 # 1103 samples: an odd window
+def test_enhancement_output_above_512_points(Engine, cfg):
+    """Speech output (sigOUT, src/io/out.cc:405-434) on 1024 .. 4096-point frames - 44.1 / 48 kHz audio: bigfft_kernel leaves the
+    frames' spectra and the magnitudes behind the NR in the plan's scratch, bigsynth_kernel transforms back, ola_kernel overlaps and
+    adds.  The bound of the 256 / 512-point path: 2 LSB, mean below 0.3."""
+    cfg = cfg.split()
+    utts = [synth_utt(160 + i, 60000 + 7111 * i) for i in range(2)] + [sig("CS0")[:50000], synth_utt(163, 9000)]
+    eng, orc = Engine(cfg), Oracle(cfg)
+    utts = [u for u in utts if len(u) >= eng.dims.window - eng.dims.wshift]
+    got = eng.enhance(utts)
+    for u, g in zip(utts, got):
+        ref = orc.enhance(u)
+        assert g.shape == ref.shape and g.dtype == np.int16
+        d = np.abs(g.astype(int) - ref.astype(int))
+        assert d.max() <= 2 and d.mean() <= 0.3, (d.max(), d.mean())
+
+
 def test_enhancement_8khz_and_api_guards(Engine):
     from ctucopy_amd import CtuError
     cfg = "-fs 8000 -format_in raw -format_out raw -preset exten".split()  # 256-point transform, two frames per FFT
