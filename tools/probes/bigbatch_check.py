@@ -15,7 +15,12 @@ CFGS = {"C3": C3, "C2_d_a_cms": C2 + ["-fea_delta", "d_a", "-fea_Z_block", "500"
         "C2_vad16_exten": C2 + "-nr_mode exten -nr_a 2 -vad burg -vad_out_mode vad -vad_cri_mode cepdist -vad_thr_mode adapt".split(),
         "C4_novad": C4_NOVAD, "fft1024_plp": C3 + ["-w", "40", "-s", "10"], "lp_noinld": C2 + "-fb_inld off -fea_kind lpc -fea_lporder 12 -fea_ncepcoefs 12".split(),
         "C2_dc1": C2 + ["-remove_dc1", "on"], "fwss8": "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -vad burg -nr_mode fwss".split(),
-        "exten_raw": "-fs 16000 -format_in raw -format_out raw -preset exten".split()}
+        "exten_raw": "-fs 16000 -format_in raw -format_out raw -preset exten".split(),
+        # round 4: exten along chains of utterances on 1024-point frames (more utterances than waves), the VAD's energy criterion there,
+        # fwss ahead of an energy column and a delta chain
+        "fft1024_exten": C2 + ["-w", "40", "-s", "10", "-nr_mode", "exten"],
+        "fft1024_vad": C2 + "-w 40 -s 10 -nr_mode exten -vad_out_mode vad -vad_cri_mode energy -vad_thr_mode adapt".split(),
+        "fwss8_E_d_a": "-fs 8000 -format_in raw -format_out htk -preset mfcc -preem 0.97 -vad burg -nr_mode fwss -fea_E on -fea_delta d_a".split()}
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(3)
 for name, cfg in CFGS.items():
