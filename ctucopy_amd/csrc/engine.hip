@@ -1318,7 +1318,9 @@ int ctu_plan_create(ctu_engine *e, const int64_t *utt_nsamples, int32_t n_utt, c
         for (int i = 0; i < n_utt; i++)
             if (uts[i + 1] > uts[i]) live.push_back(i);
         std::stable_sort(live.begin(), live.end(), [&](int a, int b) { return pl->frames[a] > pl->frames[b]; });
-        const int C = std::max(1, std::min<int>((int)live.size(), max_wg * NWAVE));
+        // (bigfft_kernel walks a chain with a whole workgroup of 256 threads: eight of them fit a CU at once)
+        const int slots = (e->big && !e->wave1k) ? e->n_cu * 8 : max_wg * NWAVE;
+        const int C = std::max(1, std::min<int>((int)live.size(), slots));
         const int G = (C + NWAVE - 1) / NWAVE;
         wg_first.assign((size_t)G * NWAVE, -1);
         std::vector<int> tail(C, -1);  // last tile of each chain so far
